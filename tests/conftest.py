@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    has_gpu = torch.cuda.is_available()
+    has_ref = os.path.isdir("/root/reference")
+    for item in items:
+        if "gpu" in item.keywords and not has_gpu:
+            item.add_marker(pytest.mark.skip(reason="no GPU in this container"))
+        if "reference" in item.keywords and not has_ref:
+            item.add_marker(pytest.mark.skip(reason="/root/reference not present"))

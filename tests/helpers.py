@@ -1,0 +1,72 @@
+"""Shared test helpers (fixtures loading, tolerances)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def micro(name):
+    """Returns (state_dict, cfg, npz) for tests/golden/micro_{deit,cait}.npz."""
+    z = load_npz(name)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    m = {k[5:]: z[k].item() for k in z.files if k.startswith("meta/")}
+    cfg = dict(arch=m["arch"], dim=m["dim"], depth=m["depth"], heads=m["heads"], reserve_layer=m["reserve_layer"],
+               reserve_k=m["reserve_k"], global_coe=m["global_coe"], num_prototypes=m["num_prototypes"],
+               proto_dim=m["proto_dim"], num_classes=m["num_classes"], global_per_class=m["global_per_class"],
+               protos_per_class=m["num_prototypes"] // m["num_classes"], img=m["img"], patch=16)
+    return sd, cfg, z
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close(a, b, rtol, atol=0.0, what=""):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} out of tol; max abs err {float(err.max()):.3e}, "
+                                 f"max rel-to-max {float(err.max() / b.abs().max().clamp_min(1e-30)):.3e}")
+
+
+def check_param_tensors(z, tag, named, rtol, atol, grad_floor=None):
+    """Compare {name: tensor} with the 'grad'/'step' entries of a micro fixture (full or sampled).
+
+    grad_floor: for the post-AdamW 'step' comparison only entries whose reference gradient magnitude
+    exceeds it are compared -- AdamW's first step is lr*g/(|g|+1e-8), i.e. it amplifies rounding noise of
+    mathematically-zero gradients (e.g. the key bias of a softmax) to a full +-lr step."""
+    n = 0
+    for name, t in named.items():
+        t = t.detach().double().cpu()
+        if f"{tag}/{name}" in z.files:
+            ref = torch.from_numpy(z[f"{tag}/{name}"]).double()
+            if grad_floor is not None:
+                m = torch.from_numpy(z[f"grad/{name}"]).abs() > grad_floor
+                t, ref = t[m], ref[m]
+            assert_close(t, ref, rtol, atol, f"{tag}/{name}")
+        elif f"{tag}_idx/{name}" in z.files:
+            idx = torch.from_numpy(z[f"{tag}_idx/{name}"])
+            tv, ref = t.reshape(-1)[idx], torch.from_numpy(z[f"{tag}_val/{name}"]).double()
+            if grad_floor is not None:
+                m = torch.from_numpy(z[f"grad_val/{name}"]).abs() > grad_floor
+                assert_close(tv[m], ref[m], rtol, atol, f"{tag}/{name} (sample)")
+                n += 1
+                continue
+            assert_close(tv, ref, rtol, atol, f"{tag}/{name} (sample)")
+            s = float(z[f"{tag}_sum/{name}"])
+            assert abs(float(t.sum()) - s) <= 1e-3 * max(1.0, float(t.abs().sum())), f"{tag}/{name} checksum"
+        else:
+            raise AssertionError(f"fixture has no {tag} entry for {name}")
+        n += 1
+    return n
