@@ -1,0 +1,62 @@
+"""ctypes binding of the C-ABI HIP library (include/ppf_hip.h).
+
+There is NO CPU or eager fallback: if the shared library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
+
+# signature spec per entry point: p = device/host pointer, i = int32, l = int64, f = float, s = hipStream_t
+SIGS = {
+    "ppf_gemm_bf16": "pppiiiiiiiiippipipppipfs",
+    "ppf_device_info": "pppi",
+}
+
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "s": ctypes.c_void_p}
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m protopformer_amd.build` "
+                               "(there is no fallback path)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ppf_last_error.restype = ctypes.c_char_p
+        _lib.ppf_abi_version.restype = ctypes.c_int
+        for name, spec in SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [_CT[c] for c in spec]
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    return x
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on the current torch stream; the stream argument is appended automatically
+    when the signature ends in 's'."""
+    L = lib()
+    spec = SIGS[name]
+    if spec.endswith("s") and len(args) == len(spec) - 1:
+        args = args + (stream_ptr(),)
+    if len(args) != len(spec):
+        raise TypeError(f"{name}: expected {len(spec)} arguments, got {len(args)}")
+    conv = [(_ptr(a) if c in "ps" else a) for a, c in zip(args, spec)]
+    rc = getattr(L, name)(*conv)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {L.ppf_last_error().decode()}")

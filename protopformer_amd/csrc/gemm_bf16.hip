@@ -1,0 +1,337 @@
+// bf16 MFMA GEMM family for gfx950 (wave64, v_mfma_f32_32x32x16_bf16), fp32 accumulate.
+//
+//   C[m][n] (+)= epilogue( sum_kc  A(m,kc) * B(n,kc) )
+//
+// Operand storage modes (template TA / TB):
+//   T = false : contraction-contiguous,  X(r,kc) = X[r*ld + kc]   (activations x[M,K], weights W[N,K])
+//   T = true  : contraction-strided,     X(r,kc) = X[kc*ld + r]   (read through ds_read_b64_tr_b16)
+// which covers the three GEMMs of a Linear layer without any transposed copies:
+//   forward  y  = x W^T       : TA=0 (x [M][K]),      TB=0 (W [N][K])
+//   dgrad    dx = dy W        : TA=0 (dy [M][N]),     TB=1 (W [N=kc][K=n'])
+//   wgrad    dW = dy^T x      : TA=1 (dy [M=kc][N]),  TB=1 (x [M=kc][K]), split over kc with fp32 atomics
+//
+// Tiling: 128x128x64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles),
+// register-staged global->LDS double buffering (one barrier per K tile), XOR-swizzled LDS images:
+//   mode 0 tile [128 r][64 kc]  (128 B rows): 16-B chunk index ^= (r>>1)&7  -> conflict-free ds_read_b128
+//   mode 1 tile [64 kc][128 r]  (256 B rows): 64-B unit index  ^= kc&3      -> conflict-free tr-reads
+// MFMA operands are swapped (first = B/n, second = A/m) so each lane ends up with 4 consecutive n of one
+// output row m: 8/16-byte row-major stores and vector bias/residual accesses.
+// blockIdx is remapped XCD-aware (n-tiles of one m-panel share an XCD's L2).
+#include "ppf_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile (either mode)
+
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_SIGMOID_F32 = 3, EPI_RESID = 4, EPI_DGELU = 5, EPI_ATOMIC = 6 };
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias;       // [N] (added before activation) or null
+    const float* res;        // EPI_RESID: fp32 residual [M][ldres]
+    int ldres;
+    const float* rowscale;   // EPI_RESID: per-sample scale, index m / rows_per_group (DropPath), or null
+    int rows_per_group;
+    const float* colscale;   // EPI_RESID: per-column scale (LayerScale gamma), or null
+    const bf16_t* aux_in;    // EPI_DGELU: pre-activation h [M][ldaux]
+    bf16_t* aux_out;         // EPI_GELU: pre-activation out; EPI_RESID: raw branch output (optional)
+    int ldaux;
+    float* colsum;           // EPI_ATOMIC + TA: sum over kc of A(m,kc) accumulated atomically into colsum[m]
+    float alpha;
+};
+
+__device__ __forceinline__ int lds_off_mode0(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }
+__device__ __forceinline__ int lds_off_mode1(int kc, int col) {
+    return kc * 256 + ((((col >> 5) ^ (kc & 3))) << 6) + ((col & 31) << 1);
+}
+
+template <bool T>
+struct TileIO {
+    // Issue the 4 x 16-byte global loads of this thread for the tile at (row0, k0).
+    static __device__ __forceinline__ void gload(uint4 (&reg)[4], const bf16_t* __restrict__ X, int ld, int R, int row0,
+                                                 int k0, int kend, int tid) {
+        if constexpr (!T) {
+            const int c16 = tid & 7, rb = tid >> 3;
+            const bool kok = (k0 + c16 * 8 + 8) <= kend;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = row0 + rb + 32 * i;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kok && r < R) v = *reinterpret_cast<const uint4*>(X + (size_t)r * ld + k0 + c16 * 8);
+                reg[i] = v;
+            }
+        } else {
+            const int c16 = tid & 15, kb = tid >> 4;
+            const int col = row0 + c16 * 8;
+            const bool cok = (col + 8) <= R;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kc = k0 + kb + 16 * i;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (cok && kc < kend) v = *reinterpret_cast<const uint4*>(X + (size_t)kc * ld + col);
+                reg[i] = v;
+            }
+        }
+    }
+    static __device__ __forceinline__ void sstore(const uint4 (&reg)[4], unsigned char* tile, int tid) {
+        if constexpr (!T) {
+            const int c16 = tid & 7, rb = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = reg[i];
+        } else {
+            const int c16 = tid & 15, kb = tid >> 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode1(kb + 16 * i, c16 * 8)) = reg[i];
+        }
+    }
+    // Fragment of the 32-row sub-tile starting at rbase for k-substep ks (16 contraction values):
+    // lane l holds row rbase+(l&31), kc = ks*16 + (l>>5)*8 + 0..7.
+    static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int rbase, int ks, int lane) {
+        if constexpr (!T) {
+            return *reinterpret_cast<const bf16x8*>(tile + lds_off_mode0(rbase + (lane & 31), ks * 2 + (lane >> 5)));
+        } else {
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
+            const int col = rbase + 16 * g16 + 4 * (s & 3);
+            const int kc = ks * 16 + 8 * h + (s >> 2);
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + lds_off_mode1(kc, col)));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + lds_off_mode1(kc + 4, col)));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, float v0, float v1, float v2, float v3) {
+    float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
+    if constexpr (EPI == EPI_ATOMIC) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(c + i, v[i]);
+        return;
+    }
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if constexpr (EPI == EPI_BF16) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    } else if constexpr (EPI == EPI_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_GELU) {
+        *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_uint2(pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3])));
+    } else if constexpr (EPI == EPI_SIGMOID_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + __expf(-v[i]));
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_RESID) {
+        if (p.aux_out)
+            *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (p.colscale) {
+            const float4 g = *reinterpret_cast<const float4*>(p.colscale + n0);
+            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+        }
+        if (p.rowscale) {
+            const float s = p.rowscale[m / p.rows_per_group];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= s;
+        }
+        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n0);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
+    } else if constexpr (EPI == EPI_DGELU) {
+        const uint2 h = *reinterpret_cast<const uint2*>(p.aux_in + (size_t)m * p.ldaux + n0);
+        const float2 h01 = unpack_bf16x2(h.x), h23 = unpack_bf16x2(h.y);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_uint2(pack_bf16x2(v[0] * gelu_erf_grad(h01.x), v[1] * gelu_erf_grad(h01.y)),
+                       pack_bf16x2(v[2] * gelu_erf_grad(h23.x), v[3] * gelu_erf_grad(h23.y)));
+    }
+}
+
+template <bool TA, bool TB, int EPI, bool COLSUM>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (vid / tiles_n) * BM, n0 = (vid % tiles_n) * BN;
+
+    // contraction range of this z-slice (split-K): multiples of BK except the tail
+    const int nsplit = gridDim.z;
+    const int kchunk = (((p.K + nsplit - 1) / nsplit) + BK - 1) / BK * BK;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(p.K, kbeg + kchunk);
+    if (kbeg >= kend) return;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    uint4 ra[4], rb[4];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 accs[2];
+    if constexpr (COLSUM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[j][r] = 0.f;
+    }
+    const bool do_colsum = COLSUM && p.colsum != nullptr && n0 == 0 && wn == 0;
+
+    TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
+    TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
+    TileIO<TA>::sstore(ra, smem, tid);
+    TileIO<TB>::sstore(rb, smem + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const unsigned char* tA = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* tB = tA + TILE_BYTES;
+        const bool more = (kt + 1) < nk;
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid);
+            TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = TileIO<TA>::frag(tA, wm + 32 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb[i] = TileIO<TB>::frag(tB, wn + 32 * i, ks, lane);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+            if constexpr (COLSUM) {
+                if (do_colsum) {
+                    bf16x8 ones;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        accs[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[mi], accs[mi], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            unsigned char* nA = smem + (buf ^ 1) * 2 * TILE_BYTES;
+            TileIO<TA>::sstore(ra, nA, tid);
+            TileIO<TB>::sstore(rb, nA + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, for each (ni, mi): row m = m0+wm+32*mi+(lane&31), and for g = 0..3 the four
+    // consecutive columns n = n0+wn+32*ni+8*g+4*(lane>>5) .. +3  (acc regs 4g..4g+3)
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm + 32 * mi + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn + 32 * ni + 8 * g + 4 * h;
+                if (n < p.N)
+                    epilogue4<EPI>(p, m, n, acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+            }
+        }
+        if constexpr (COLSUM) {
+            if (do_colsum && h == 0) unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
+        }
+    }
+}
+
+template <bool TA, bool TB, int EPI, bool COLSUM>
+int launch(const GemmParams& p, int splitk, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    auto kern = gemm_kernel<TA, TB, EPI, COLSUM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splitk), dim3(NTHREADS), 4 * TILE_BYTES, stream, p);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int pick_splitk(int M, int N, int K) {
+    // wgrad-style problems (small output, very long contraction): spread over ~2 workgroups per CU
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int s = (512 + tiles - 1) / tiles;
+    const int maxs = (K + 4 * BK - 1) / (4 * BK);      // at least 4 K-tiles per slice
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
+// epi: 0 bf16 out, 1 f32 out, 2 bias+GELU (C = gelu bf16, aux_out = pre-activation bf16), 3 sigmoid f32 out,
+//      4 residual (C f32 = res + rowscale*colscale*(acc+bias), optional aux_out raw bf16), 5 dGELU (C bf16 = acc*gelu'(aux_in)),
+//      6 atomic f32 accumulate into C (split over the contraction; optional colsum of A when trans_a).
+int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                  int trans_b, int epi, const float* bias, const float* res, int ldres, const float* rowscale,
+                  int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,
+                  float alpha, hipStream_t stream) {
+    PPF_CHECK_ARG(M > 0 && N > 0 && K > 0, PPF_ERR_SHAPE, "ppf_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    PPF_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && (N % 4) == 0, PPF_ERR_ALIGN,
+                  "ppf_gemm_bf16: lda/ldb must be multiples of 8, ldc and N of 4 (lda=%d ldb=%d ldc=%d N=%d)", lda, ldb, ldc, N);
+    PPF_CHECK_ARG(trans_a ? (M % 8 == 0) : (K % 8 == 0), PPF_ERR_ALIGN, "ppf_gemm_bf16: A inner extent must be a multiple of 8");
+    PPF_CHECK_ARG(trans_b ? (N % 8 == 0) : (K % 8 == 0), PPF_ERR_ALIGN, "ppf_gemm_bf16: B inner extent must be a multiple of 8");
+    PPF_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, PPF_ERR_ALIGN, "ppf_gemm_bf16: pointers must be 16-byte aligned");
+    PPF_CHECK_ARG(!(trans_a && !trans_b), PPF_ERR_ARG, "ppf_gemm_bf16: (trans_a=1, trans_b=0) is not instantiated");
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+    p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha;
+    if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
+    if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
+    if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
+    if (!trans_a && !trans_b) {
+        switch (epi) {
+            case EPI_BF16: return launch<false, false, EPI_BF16, false>(p, 1, stream);
+            case EPI_F32: return launch<false, false, EPI_F32, false>(p, 1, stream);
+            case EPI_GELU: return launch<false, false, EPI_GELU, false>(p, 1, stream);
+            case EPI_SIGMOID_F32: return launch<false, false, EPI_SIGMOID_F32, false>(p, 1, stream);
+            case EPI_RESID: return launch<false, false, EPI_RESID, false>(p, 1, stream);
+            default: break;
+        }
+    } else if (!trans_a && trans_b) {
+        switch (epi) {
+            case EPI_BF16: return launch<false, true, EPI_BF16, false>(p, 1, stream);
+            case EPI_F32: return launch<false, true, EPI_F32, false>(p, 1, stream);
+            case EPI_DGELU: return launch<false, true, EPI_DGELU, false>(p, 1, stream);
+            default: break;
+        }
+    } else {
+        switch (epi) {
+            case EPI_ATOMIC: return launch<true, true, EPI_ATOMIC, true>(p, pick_splitk(M, N, K), stream);
+            case EPI_F32: return launch<true, true, EPI_F32, false>(p, 1, stream);
+            default: break;
+        }
+    }
+    ppf_set_error("ppf_gemm_bf16: combination trans_a=%d trans_b=%d epi=%d not instantiated", trans_a, trans_b, epi);
+    return PPF_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""GPU parity of the bf16 MFMA GEMM family vs a plain fp32 torch reference on the same bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (scale * torch.randn(shape, generator=g)).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (394, 1152, 384), (1000, 200, 192), (128, 384, 1536), (77, 64, 72)])
+def test_gemm_nt_bf16_and_f32(M, N, K):
+    from protopformer_amd import ops
+    a = _mk((M, K), 1.0, 1).bfloat16()
+    b = _mk((N, K), 0.1, 2).bfloat16()
+    bias = _mk((N,), 0.5, 3)
+    ref = a.float() @ b.float().t() + bias
+    out = ops.gemm(a, b, epi=ops.EPI_F32, bias=bias)
+    assert_close(out, ref, rtol=1e-3, atol=1e-3, what="gemm f32")      # 1e-3 rel (north_star), K-term fp32 accumulation
+    out16 = ops.gemm(a, b, epi=ops.EPI_BF16, bias=bias)
+    assert_close(out16.float(), ref.bfloat16().float(), rtol=8e-3, atol=1e-3, what="gemm bf16 out")
+
+
+def test_gemm_transpose_detecting():
+    """Asymmetric operands: an (m,n)-swapped write or a k-permutation mismatch between A and B cannot pass."""
+    from protopformer_amd import ops
+    M, N, K = 128, 128, 64
+    a = torch.zeros(M, K); b = torch.zeros(N, K)
+    for m in range(M):
+        a[m, m % K] = 1.0 + (m % 7)
+    for n in range(N):
+        b[n, (3 * n + 1) % K] = 2.0 + (n % 5)
+    ref = a @ b.t()
+    out = ops.gemm(a.cuda().bfloat16(), b.cuda().bfloat16(), epi=ops.EPI_F32)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_gelu_sigmoid_resid():
+    from protopformer_amd import ops
+    M, N, K = 394, 768, 192
+    a = _mk((M, K), 1.0, 1).bfloat16(); b = _mk((N, K), 0.1, 2).bfloat16(); bias = _mk((N,), 0.5, 3)
+    pre = a.float() @ b.float().t() + bias
+    h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    g = ops.gemm(a, b, epi=ops.EPI_GELU, bias=bias, aux_out=h)
+    assert_close(h.float(), pre.bfloat16().float(), rtol=8e-3, atol=1e-3, what="pre-activation")
+    assert_close(g.float(), torch.nn.functional.gelu(pre).bfloat16().float(), rtol=8e-3, atol=2e-3, what="gelu")
+    s = ops.gemm(a, b, epi=ops.EPI_SIGMOID_F32, bias=bias)
+    assert_close(s, torch.sigmoid(pre), rtol=1e-3, atol=1e-4, what="sigmoid")
+    # residual epilogue with per-sample DropPath scale and LayerScale
+    rows_per = 197
+    res = _mk((M, N), 1.0, 4); rs = torch.tensor([0.0, 1.0 / 0.9], device="cuda"); cs = _mk((N,), 0.3, 5)
+    raw = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(a, b, epi=ops.EPI_RESID, bias=bias, res=res, rowscale=rs, rows_per_group=rows_per, colscale=cs, aux_out=raw)
+    ridx = torch.arange(M, device="cuda") // rows_per
+    ref = res + pre * cs * rs[ridx][:, None]
+    assert_close(out, ref, rtol=1e-3, atol=2e-3, what="residual epilogue")
+    assert_close(raw.float(), pre.bfloat16().float(), rtol=8e-3, atol=1e-3, what="raw branch output")
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 384, 1152), (300, 192, 576), (128, 1536, 384)])
+def test_gemm_dgrad_nn(M, N, K):
+    """dx[M,N] = dy[M,K] @ W[K,N]  (B stored [kc][n] -> trans_b)."""
+    from protopformer_amd import ops
+    dy = _mk((M, K), 1.0, 1).bfloat16(); w = _mk((K, N), 0.1, 2).bfloat16()
+    ref = dy.float() @ w.float()
+    out = ops.gemm(dy, w, trans_b=True, epi=ops.EPI_F32)
+    assert_close(out, ref, rtol=1e-3, atol=2e-3, what="dgrad")
+    hpre = _mk((M, N), 1.0, 3).bfloat16()
+    out2 = ops.gemm(dy, w, trans_b=True, epi=ops.EPI_DGELU, aux_in=hpre)
+    x = hpre.float()
+    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    assert_close(out2.float(), (ref * gp).bfloat16().float(), rtol=1e-2, atol=3e-3, what="dgelu")
+
+
+@pytest.mark.parametrize("R,N,K", [(1000, 384, 384), (50432 // 8, 1152, 384), (777 * 8, 192, 768)])
+def test_gemm_wgrad_tn_atomic(R, N, K):
+    """dW[N,K] += dy[R,N]^T @ x[R,K] with split contraction + fp32 atomics, fused bias grad (column sum of dy)."""
+    from protopformer_amd import ops
+    dy = _mk((R, N), 1.0, 1).bfloat16(); x = _mk((R, K), 1.0, 2).bfloat16()
+    ref = dy.float().t() @ x.float()
+    dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    ops.gemm(dy, x, trans_a=True, trans_b=True, epi=ops.EPI_ATOMIC, out=dw, colsum=db)
+    scale = float(ref.abs().max())
+    assert_close(dw, ref, rtol=1e-3, atol=1e-3 * scale, what="wgrad")
+    assert_close(db, dy.float().sum(0), rtol=1e-3, atol=1e-3 * float(dy.float().sum(0).abs().max()), what="bias grad")
+    # accumulates (+=) into existing contents
+    ops.gemm(dy, x, trans_a=True, trans_b=True, epi=ops.EPI_ATOMIC, out=dw)
+    assert_close(dw, 2 * ref, rtol=1e-3, atol=2e-3 * scale, what="wgrad accumulate")
