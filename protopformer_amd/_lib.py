@@ -13,6 +13,16 @@ LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
 SIGS = {
     "ppf_gemm_bf16": "pppiiiiiiiiippipipppipfs",
     "ppf_device_info": "pppi",
+    "ppf_layernorm_fwd": "ppppppp" "iif" "s",
+    "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "s",
+    "ppf_cast_f32_bf16": "ppls",
+    "ppf_im2col_patch": "ppiiiiis",
+    "ppf_assemble_tokens": "ppppiiiis",
+    "ppf_assemble_tokens_bwd": "ppppiiiis",
+    "ppf_adamw_step": "pppppp" "li" "ppp" "fff" "i" "ff" "s",
+    "ppf_attn_fwd": "ppppp" "iiiii" "s",
+    "ppf_attn_headmean": "ppppp" "i" "iiiii" "s",
+    "ppf_attn_bwd": "pppppppp" "iiiii" "s",
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "s": ctypes.c_void_p}

@@ -1,0 +1,506 @@
+// Multi-head attention with the reference's policy softmax (tools/deit_models_attn.py:29-60), gfx950.
+//
+// Sequence length is tiny (N = 197 / 196, <= 224), so one wavefront keeps a whole 32-query x N-key score
+// strip in registers: no online-softmax rescaling, one pass.  All contractions run on
+// v_mfma_f32_32x32x16_bf16 with the "swapped" operand order (first = keys / d, second = queries), so every
+// lane owns ONE query row (lane&31) and the softmax reductions are in-lane + one cross-half shuffle.
+// K and V of one (batch, head) are staged once per workgroup in LDS as [key][128 B] rows with an XOR chunk
+// swizzle that is conflict-free for BOTH access styles used here:
+//   ds_read_b128  (K as MFMA A operand for Q.K^T, contraction over d)
+//   ds_read_b64_tr_b16 (V / K / Q / dO read "transposed": contraction over keys or queries)
+// Kernels:
+//   attn_fwd      O = softmax_policy(Q K^T * scale) V, saves row max and 1/(sum+eps) per (b,h,q)
+//   attn_headmean mean over heads of the probabilities -> (B, N, NP) fp32 (rollout input), recomputed from
+//                 the saved statistics (no B*H*N*N tensor ever exists)
+//   attn_bwd_dq   dQ (+ delta = rowsum(dO*O)),  one wave per 32-query tile
+//   attn_bwd_dkv  dK, dV,                        one wave per 32-key tile
+#include "ppf_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr float SOFTMAX_EPS = 1e-6f;     // deit:29 eps
+
+struct AttnParams {
+    const bf16_t* qkv;     // [B*N][ld] : q | k | v at column offsets 0, D, 2D (+ h*HD)
+    int ld;                // 3*D
+    bf16_t* out;           // [B*N][D]
+    const float* policy;   // [B][N] in {0,1} or null (all ones)
+    float* rowmax;         // [B][H][N]
+    float* zinv;           // [B][H][N]   1/(sum+eps)
+    float* headmean;       // [B][N][NP] fp32
+    int NP;
+    // backward
+    const bf16_t* dout;    // [B*N][D]
+    bf16_t* dqkv;          // [B*N][ld]
+    float* delta;          // [B][H][N]
+    int B, H, N, D;
+    int self_keep;         // 1: a masked query still attends to itself (DeiT); 0: CaiT class attention
+    float scale;
+};
+
+__device__ __forceinline__ int kswz(int row) {
+    const int u = row >> 1;
+    return ((u & 1) << 2) | (((u >> 2) & 1) << 1) | ((u >> 1) & 1);
+}
+__device__ __forceinline__ int row_off(int row, int c16) { return row * 128 + ((c16 ^ kswz(row)) << 4); }
+
+// MFMA A/B fragment, contraction-contiguous rows: lane -> row base+(lane&31), 8 values at d = ks*16 + (lane>>5)*8
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* tile, int base, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + row_off(base + (lane & 31), ks * 2 + (lane >> 5)));
+}
+// MFMA A fragment read transposed: output index = d (dbase + lane&31), contraction slots = rows.
+// Slot order matches the natural register order of a swapped-operand score tile:
+//   slot (h, jj) <-> row kb + (jj&3) + 8*(jj>>2) + 4*h
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int kb, int dbase, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
+    const int d = dbase + 16 * g16 + 4 * (s & 3);
+    const int r0 = kb + 4 * h + (s >> 2), r1 = r0 + 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + row_off(r0, d >> 3) + ((d & 7) << 1)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + row_off(r1, d >> 3) + ((d & 7) << 1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int o) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 u = {pack_bf16x2(v[o], v[o + 1]), pack_bf16x2(v[o + 2], v[o + 3]), pack_bf16x2(v[o + 4], v[o + 5]), pack_bf16x2(v[o + 6], v[o + 7])};
+    return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ int reg_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Stage `rows` rows (HD bf16 each) from src (row stride ld) into a swizzled LDS tile.  Rows beyond nvalid are
+// zero-filled, or (CLAMP) replicate the last valid row so that padded keys produce finite scores that never
+// exceed the true row maximum (they are then removed by keep = 0).
+template <int HD, bool CLAMP>
+__device__ __forceinline__ void stage_rows(unsigned char* tile, const bf16_t* src, int ld, int row_begin, int rows, int nvalid, int tid) {
+    constexpr int CH = HD / 8;
+    for (int i = tid; i < rows * CH; i += 256) {
+        const int r = i / CH, c = i - r * CH;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        int gr = row_begin + r;
+        if (CLAMP) gr = min(gr, nvalid - 1);
+        if (gr < nvalid) v = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + c * 8);
+        *reinterpret_cast<uint4*>(tile + row_off(r, c)) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int HD, int NT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + NT * 32 * 4];
+    unsigned char* tK = lds;
+    unsigned char* tV = lds + NT * 32 * 128;
+    float* pol = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);     // keep flag per key (0 for padding)
+    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
+    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
+    const float c = SOFTMAX_EPS / (float)N;
+    stage_rows<HD, true>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
+    stage_rows<HD, false>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
+    for (int i = tid; i < NT * 32; i += 256) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+    __syncthreads();
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= N) return;
+    const int q = q0 + (lane & 31), qc = min(q, N - 1);
+    const int qself = p.self_keep ? q : -1;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
+    f32x16 s[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[t][r] *= p.scale;
+            mx = fmaxf(mx, s[t][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // one tile's K fragments in flight at a time (register pressure)
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = t * 32 + 8 * g + 4 * hh;
+            const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
+            const float keep[4] = {kp.x, kp.y, kp.z, kp.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float k = (key0 + i == qself) ? 1.0f : keep[i];
+                const float e = __expf(s[t][4 * g + i] - mx) * k;
+                sum += e;
+                s[t][4 * g + i] = e + c;              // unnormalised probability (+eps/N); padded keys hit zero V rows
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 pf = pack8(s[t], 8 * st);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, t * 32 + 16 * st, dt * 32, lane), pf, o[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the per-tile policy reads from being hoisted (register pressure)
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float zi = 1.0f / (sum + SOFTMAX_EPS);
+    if (hh == 0 && q < N) {
+        const size_t si = ((size_t)b * p.H + h) * N + q;
+        p.rowmax[si] = mx;
+        p.zinv[si] = zi;
+    }
+    if (q < N) {
+        bf16_t* orow = p.out + ((size_t)b * N + q) * p.D + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hh;
+                if (d < HD)
+                    *reinterpret_cast<uint2*>(orow + d) = make_uint2(pack_bf16x2(o[dt][4 * g] * zi, o[dt][4 * g + 1] * zi),
+                                                                     pack_bf16x2(o[dt][4 * g + 2] * zi, o[dt][4 * g + 3] * zi));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- head mean
+// grid: x = 128-query block, y = KT*32-key block, z = batch.  Loops over heads, K tile restaged per head.
+template <int HD, int KT>
+__global__ __launch_bounds__(256, 2) void attn_headmean_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char tK[KT * 32 * 128];
+    __shared__ __attribute__((aligned(16))) float pol[KT * 32];
+    __shared__ __attribute__((aligned(16))) float cv[KT * 32];
+    constexpr int KS = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, N = p.N, key_begin = blockIdx.y * KT * 32;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q = q0 + (lane & 31), qc = min(q, N - 1);
+    const bool active = q0 < N;
+    const float c = SOFTMAX_EPS / (float)N;
+    for (int i = tid; i < KT * 32; i += 256) {
+        const int key = key_begin + i;
+        pol[i] = (key < N) ? (p.policy ? p.policy[(size_t)b * N + key] : 1.0f) : 0.0f;
+        cv[i] = (key < N) ? c : 0.0f;
+    }
+    const int qself = p.self_keep ? q : -1;
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int h = 0; h < p.H; ++h) {
+        const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
+        __syncthreads();
+        stage_rows<HD, true>(tK, base + p.D, p.ld, key_begin, KT * 32, N, tid);
+        __syncthreads();
+        if (!active) continue;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
+        const size_t si = ((size_t)b * p.H + h) * N + qc;
+        const float mx = p.rowmax[si], zi = p.zinv[si];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kl = t * 32 + 8 * g + 4 * hh;
+                const float4 kp = *reinterpret_cast<const float4*>(pol + kl);
+                const float4 cq = *reinterpret_cast<const float4*>(cv + kl);
+                const float keep[4] = {kp.x, kp.y, kp.z, kp.w}, cc[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float k = (key_begin + kl + i == qself) ? 1.0f : keep[i];
+                    acc[t][4 * g + i] += (__expf(s[4 * g + i] * p.scale - mx) * k + cc[i]) * zi;
+                }
+            }
+        }
+    }
+    if (active && q < N) {
+        const float invH = 1.0f / (float)p.H;
+        float* row = p.headmean + ((size_t)b * N + q) * p.NP;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key = key_begin + t * 32 + 8 * g + 4 * hh;
+                if (key < p.NP)
+                    *reinterpret_cast<float4*>(row + key) = make_float4(acc[t][4 * g] * invH, acc[t][4 * g + 1] * invH, acc[t][4 * g + 2] * invH, acc[t][4 * g + 3] * invH);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+template <int HD, int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + NT * 32 * 4];
+    unsigned char* tK = lds;
+    unsigned char* tV = lds + NT * 32 * 128;
+    float* pol = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);
+    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
+    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
+    stage_rows<HD, true>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
+    stage_rows<HD, false>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
+    for (int i = tid; i < NT * 32; i += 256) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+    __syncthreads();
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= N) return;
+    const int q = q0 + (lane & 31), qc = min(q, N - 1);
+    const int qself = p.self_keep ? q : -1;
+    bf16x8 qf[KS], dof[KS];
+    float dl = 0.f;
+    {
+        const bf16_t* dorow = p.dout + ((size_t)b * N + qc) * p.D + h * HD;
+        const bf16_t* orow = p.out + ((size_t)b * N + qc) * p.D + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dorow + ks * 16 + hh * 8);
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ov[e];
+        }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const size_t si = ((size_t)b * p.H + h) * N + qc;
+    const float mx = p.rowmax[si], zi = p.zinv[si];
+    if (hh == 0 && q < N) p.delta[si] = dl;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        f32x16 s, g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tV, t * 32, ks, lane), dof[ks], g, 0, 0, 0);
+        }
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int key0 = t * 32 + 8 * gg + 4 * hh;
+            const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
+            const float keep[4] = {kp.x, kp.y, kp.z, kp.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float k = (key0 + i == qself) ? 1.0f : keep[i];
+                const float pt = __expf(s[4 * gg + i] * p.scale - mx) * k * zi;   // padded keys: keep = 0
+                s[4 * gg + i] = pt * (g[4 * gg + i] - dl);           // dS (before the scale factor)
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 dsf = pack8(s, 8 * st);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, t * 32 + 16 * st, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+        }
+    }
+    if (q < N) {
+        bf16_t* row = p.dqkv + ((size_t)b * N + q) * p.ld + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hh;
+                if (d < HD)
+                    *reinterpret_cast<uint2*>(row + d) = make_uint2(pack_bf16x2(dq[dt][4 * g] * p.scale, dq[dt][4 * g + 1] * p.scale),
+                                                                    pack_bf16x2(dq[dt][4 * g + 2] * p.scale, dq[dt][4 * g + 3] * p.scale));
+            }
+    }
+}
+
+// --------------------------------------------------------------------------------------- backward: dK, dV
+template <int HD, int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + 3 * NT * 32 * 4];
+    unsigned char* tQ = lds;
+    unsigned char* tO = lds + NT * 32 * 128;
+    float* st_m = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);
+    float* st_z = st_m + NT * 32;
+    float* st_d = st_z + NT * 32;
+    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
+    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
+    stage_rows<HD, false>(tQ, base, p.ld, 0, NT * 32, N, tid);
+    stage_rows<HD, false>(tO, p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, NT * 32, N, tid);
+    for (int i = tid; i < NT * 32; i += 256) {
+        const size_t si = ((size_t)b * p.H + h) * N + i;
+        st_m[i] = i < N ? p.rowmax[si] : 0.f;
+        st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
+        st_d[i] = i < N ? p.delta[si] : 0.f;
+    }
+    __syncthreads();
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    if (k0 >= N) return;
+    const int key = k0 + (lane & 31), kc = min(key, N - 1);
+    const float keep_key = key < N ? (p.policy ? p.policy[(size_t)b * N + kc] : 1.0f) : 0.f;
+    const int kself = p.self_keep ? key : -1;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(base + p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
+    }
+    const float c = SOFTMAX_EPS / (float)N;
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        f32x16 s, g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tQ, t * 32, ks, lane), kf[ks], s, 0, 0, 0);   // [q][key]
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tO, t * 32, ks, lane), vf[ks], g, 0, 0, 0);   // dO.V^T
+        }
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int qq0 = t * 32 + 8 * gg + 4 * hh;
+            const float4 m4 = *reinterpret_cast<const float4*>(st_m + qq0), z4 = *reinterpret_cast<const float4*>(st_z + qq0),
+                         d4 = *reinterpret_cast<const float4*>(st_d + qq0);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float k = (qq0 + i == kself) ? 1.0f : keep_key;
+                const float pt = __expf(s[4 * gg + i] * p.scale - mm[i]) * k * zz[i];
+                s[4 * gg + i] = pt * (g[4 * gg + i] - dd[i]);          // dS[q][key]
+                g[4 * gg + i] = pt + c * zz[i];                         // out[q][key]
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8 dsf = pack8(s, 8 * st), pf = pack8(g, 8 * st);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, t * 32 + 16 * st, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tO, t * 32 + 16 * st, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (key < N) {
+        bf16_t* krow = p.dqkv + ((size_t)b * N + key) * p.ld + p.D + h * HD;
+        bf16_t* vrow = krow + p.D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hh;
+                if (d < HD) {
+                    *reinterpret_cast<uint2*>(krow + d) = make_uint2(pack_bf16x2(dk[dt][4 * g] * p.scale, dk[dt][4 * g + 1] * p.scale),
+                                                                     pack_bf16x2(dk[dt][4 * g + 2] * p.scale, dk[dt][4 * g + 3] * p.scale));
+                    *reinterpret_cast<uint2*>(vrow + d) = make_uint2(pack_bf16x2(dv[dt][4 * g], dv[dt][4 * g + 1]), pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]));
+                }
+            }
+    }
+}
+
+template <typename F>
+int dispatch(int hd, int N, const char* who, F&& f) {
+    const int nt = (N + 31) / 32;
+#define PPF_HD_CASE(HDV)                                                         \
+    if (hd == HDV) {                                                             \
+        if (nt <= 1) return f(std::integral_constant<int, HDV>(), std::integral_constant<int, 1>()); \
+        if (nt <= 2) return f(std::integral_constant<int, HDV>(), std::integral_constant<int, 2>()); \
+        if (nt <= 4) return f(std::integral_constant<int, HDV>(), std::integral_constant<int, 4>()); \
+        if (nt <= 7) return f(std::integral_constant<int, HDV>(), std::integral_constant<int, 7>()); \
+    }
+    PPF_HD_CASE(64)
+    PPF_HD_CASE(48)
+    PPF_HD_CASE(32)
+#undef PPF_HD_CASE
+    ppf_set_error("%s: unsupported head_dim=%d / tokens=%d (head_dim in {32,48,64}, tokens <= 224)", who, hd, N);
+    return PPF_ERR_SHAPE;
+}
+
+int fill(AttnParams& p, const void* qkv, int B, int H, int N, int D, const float* policy, float* rowmax, float* zinv, int self_keep, const char* who) {
+    PPF_CHECK_ARG(B > 0 && H > 0 && N > 0 && D > 0 && D % H == 0 && (D % 8) == 0, PPF_ERR_SHAPE, "%s: bad shape B=%d H=%d N=%d D=%d", who, B, H, N, D);
+    PPF_CHECK_ARG(qkv && rowmax && zinv, PPF_ERR_ARG, "%s: null pointer", who);
+    p = AttnParams();
+    p.qkv = (const bf16_t*)qkv; p.ld = 3 * D; p.policy = policy; p.rowmax = rowmax; p.zinv = zinv; p.B = B; p.H = H; p.N = N; p.D = D;
+    p.self_keep = self_keep; p.scale = 1.0f / sqrtf((float)(D / H));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// O[B*N][D] = softmax_policy(Q K^T / sqrt(hd)) V from packed qkv [B*N][3D]; saves rowmax and 1/(sum+eps) [B][H][N].
+int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, int B, int H, int N, int D, int self_keep,
+                 hipStream_t stream) {
+    AttnParams p;
+    int rc = fill(p, qkv, B, H, N, D, policy, rowmax, zinv, self_keep, "ppf_attn_fwd");
+    if (rc) return rc;
+    p.out = (bf16_t*)out;
+    return dispatch(D / H, N, "ppf_attn_fwd", [&](auto hd, auto nt) {
+        hipLaunchKernelGGL((attn_fwd_kernel<decltype(hd)::value, decltype(nt)::value>), dim3((N + 127) / 128, H, B), dim3(256), 0, stream, p);
+        PPF_LAUNCH_CHECK();
+        return 0;
+    });
+}
+
+// headmean[B][N][NP] = mean_h probabilities (NP = N rounded up to a multiple of 4; pad columns are written as 0).
+int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax, const float* zinv, float* headmean, int NP, int B, int H,
+                      int N, int D, int self_keep, hipStream_t stream) {
+    AttnParams p;
+    int rc = fill(p, qkv, B, H, N, D, policy, (float*)rowmax, (float*)zinv, self_keep, "ppf_attn_headmean");
+    if (rc) return rc;
+    PPF_CHECK_ARG(NP >= N && NP % 4 == 0 && NP < N + 4, PPF_ERR_SHAPE, "ppf_attn_headmean: NP=%d must be N rounded up to a multiple of 4", NP);
+    p.headmean = headmean; p.NP = NP;
+    const int hd = D / H;
+    constexpr int KT = 4;
+    dim3 grid((N + 127) / 128, (N + KT * 32 - 1) / (KT * 32), B);
+    if (hd == 64) hipLaunchKernelGGL((attn_headmean_kernel<64, KT>), grid, dim3(256), 0, stream, p);
+    else if (hd == 48) hipLaunchKernelGGL((attn_headmean_kernel<48, KT>), grid, dim3(256), 0, stream, p);
+    else if (hd == 32) hipLaunchKernelGGL((attn_headmean_kernel<32, KT>), grid, dim3(256), 0, stream, p);
+    else { ppf_set_error("ppf_attn_headmean: unsupported head_dim=%d", hd); return PPF_ERR_SHAPE; }
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dqkv[B*N][3D] from dout[B*N][D]; needs out, rowmax, zinv of the forward; delta[B][H][N] is scratch.
+int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, const float* policy, const float* rowmax,
+                 const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, hipStream_t stream) {
+    AttnParams p;
+    int rc = fill(p, qkv, B, H, N, D, policy, (float*)rowmax, (float*)zinv, self_keep, "ppf_attn_bwd");
+    if (rc) return rc;
+    PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
+    p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
+    return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
+        dim3 grid((N + 127) / 128, H, B);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(256), 0, stream, p);
+        PPF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(256), 0, stream, p);
+        PPF_LAUNCH_CHECK();
+        return 0;
+    });
+}
+
+}  // extern "C"

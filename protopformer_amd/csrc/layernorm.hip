@@ -1,0 +1,210 @@
+// LayerNorm forward / backward (fp32 residual stream in, bf16 activations out) for gfx950.
+// One wavefront per row: lane l owns the column pairs c = 2*l + 128*j (coalesced 512-B segments),
+// row statistics by wave shuffles, two-pass variance in registers.  HBM-bound streaming kernels.
+#include "ppf_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int WAVES = 4;          // rows processed concurrently per 256-thread workgroup
+constexpr int MAXJ = 8;           // D <= 1024
+
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ row_map,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 wv[NJ], bv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = 2 * lane + 128 * j;
+        wv[j] = c < D ? *reinterpret_cast<const float2*>(w + c) : make_float2(0.f, 0.f);
+        bv[j] = c < D ? *reinterpret_cast<const float2*>(b + c) : make_float2(0.f, 0.f);
+    }
+    const float invD = 1.0f / (float)D;
+    for (int r = blockIdx.x * WAVES + wave; r < rows; r += gridDim.x * WAVES) {
+        const size_t src = row_map ? (size_t)row_map[r] : (size_t)r;
+        const float* xr = x + src * D;
+        float2 v[NJ];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = 2 * lane + 128 * j;
+            v[j] = c < D ? *reinterpret_cast<const float2*>(xr + c) : make_float2(0.f, 0.f);
+            s += v[j].x + v[j].y;
+        }
+        const float mu = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = 2 * lane + 128 * j;
+            if (c < D) { const float a = v[j].x - mu, bb = v[j].y - mu; q += a * a + bb * bb; }
+        }
+        const float rs = rsqrtf(wave_sum(q) * invD + eps);
+        bf16_t* yr = y + (size_t)r * D;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = 2 * lane + 128 * j;
+            if (c < D)
+                *reinterpret_cast<uint32_t*>(yr + c) =
+                    pack_bf16x2((v[j].x - mu) * rs * wv[j].x + bv[j].x, (v[j].y - mu) * rs * wv[j].y + bv[j].y);
+        }
+        if (lane == 0) { mean_out[r] = mu; rstd_out[r] = rs; }
+    }
+}
+
+struct LnBwdParams {
+    const bf16_t* dy; const float* x; const int* row_map; const float* w; const float* mean; const float* rstd;
+    const float* dres_in; float* dx_out; float* dw; float* db;
+    bf16_t* cast_out; const float* rowscale; int rows_per_group; const float* colscale; float* dbias_next;
+    const bf16_t* branch; float* dcolscale;
+    int rows, D;
+};
+
+// dx_out[src] = dres_in[src] + LN'(dy);  dw += sum dy*xhat;  db += sum dy;
+// optional fused cast for the residual branch below: cast_out = bf16(rowscale*colscale*dx_out), its column
+// sums (bias grad of the branch GEMM) and the LayerScale grad sum(rowscale*dx_out*branch).
+// With dy == nullptr the LN part is skipped (pure scale/cast/column-sum pass over dres_in).
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
+    __shared__ float red[WAVES][NJ * 2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = p.D;
+    float2 wv[NJ], cs[NJ];
+    float2 adw[NJ], adb[NJ], anb[NJ], acs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = 2 * lane + 128 * j;
+        wv[j] = (p.dy && c < D) ? *reinterpret_cast<const float2*>(p.w + c) : make_float2(0.f, 0.f);
+        cs[j] = (p.colscale && c < D) ? *reinterpret_cast<const float2*>(p.colscale + c) : make_float2(1.f, 1.f);
+        adw[j] = adb[j] = anb[j] = acs[j] = make_float2(0.f, 0.f);
+    }
+    const float invD = 1.0f / (float)D;
+    for (int r = blockIdx.x * WAVES + wave; r < p.rows; r += gridDim.x * WAVES) {
+        const size_t src = p.row_map ? (size_t)p.row_map[r] : (size_t)r;
+        float2 dx[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = 2 * lane + 128 * j;
+            dx[j] = (p.dres_in && c < D) ? *reinterpret_cast<const float2*>(p.dres_in + src * D + c) : make_float2(0.f, 0.f);
+        }
+        if (p.dy) {
+            const float mu = p.mean[r], rs = p.rstd[r];
+            float2 xh[NJ], g[NJ];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = 2 * lane + 128 * j;
+                if (c < D) {
+                    const float2 xv = *reinterpret_cast<const float2*>(p.x + src * D + c);
+                    const float2 dyv = unpack_bf16x2(*reinterpret_cast<const uint32_t*>(p.dy + (size_t)r * D + c));
+                    xh[j] = make_float2((xv.x - mu) * rs, (xv.y - mu) * rs);
+                    g[j] = make_float2(dyv.x * wv[j].x, dyv.y * wv[j].y);
+                    s1 += g[j].x + g[j].y;
+                    s2 += g[j].x * xh[j].x + g[j].y * xh[j].y;
+                    adw[j].x += dyv.x * xh[j].x; adw[j].y += dyv.y * xh[j].y;
+                    adb[j].x += dyv.x; adb[j].y += dyv.y;
+                } else {
+                    xh[j] = g[j] = make_float2(0.f, 0.f);
+                }
+            }
+            const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                dx[j].x += rs * (g[j].x - c1 - xh[j].x * c2);
+                dx[j].y += rs * (g[j].y - c1 - xh[j].y * c2);
+            }
+        }
+        const float rsc = p.rowscale ? p.rowscale[src / p.rows_per_group] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = 2 * lane + 128 * j;
+            if (c < D) {
+                if (p.dx_out) *reinterpret_cast<float2*>(p.dx_out + src * D + c) = dx[j];
+                if (p.cast_out) {
+                    const float sx = dx[j].x * rsc, sy = dx[j].y * rsc;
+                    if (p.branch) {
+                        const float2 br = unpack_bf16x2(*reinterpret_cast<const uint32_t*>(p.branch + src * D + c));
+                        acs[j].x += sx * br.x; acs[j].y += sy * br.y;
+                    }
+                    const uint32_t pk = pack_bf16x2(sx * cs[j].x, sy * cs[j].y);
+                    *reinterpret_cast<uint32_t*>(p.cast_out + src * D + c) = pk;
+                    const float2 rt = unpack_bf16x2(pk);
+                    anb[j].x += rt.x; anb[j].y += rt.y;
+                }
+            }
+        }
+    }
+    // workgroup reduction of the column partial sums, then one atomic per column per workgroup
+    auto flush = [&](float2 (&a)[NJ], float* dst) {
+        if (!dst) return;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { red[wave][(j * 64 + lane) * 2] = a[j].x; red[wave][(j * 64 + lane) * 2 + 1] = a[j].y; }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NJ * 128; i += 256) {
+            const int j = i >> 7, rem = i & 127, l = rem >> 1, e = rem & 1;
+            const int c = 2 * l + 128 * j + e;
+            if (c < D) {
+                float s = 0.f;
+#pragma unroll
+                for (int wv_ = 0; wv_ < WAVES; ++wv_) s += red[wv_][i];
+                unsafeAtomicAdd(dst + c, s);
+            }
+        }
+    };
+    if (p.dy) { flush(adw, p.dw); flush(adb, p.db); }
+    if (p.cast_out) { flush(anb, p.dbias_next); if (p.branch) flush(acs, p.dcolscale); }
+}
+
+template <typename F>
+int dispatch_nj(int D, F&& f) {
+    const int nj = (D + 127) / 128;
+    switch (nj) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 3: return f(std::integral_constant<int, 3>());
+        case 4: return f(std::integral_constant<int, 4>());
+        case 6: return f(std::integral_constant<int, 6>());
+        case 8: return f(std::integral_constant<int, 8>());
+        default: break;
+    }
+    ppf_set_error("layernorm: unsupported width D=%d (need D even, ceil(D/128) in {1,2,3,4,6,8})", D);
+    return PPF_ERR_SHAPE;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppf_layernorm_fwd(const float* x, const int* row_map, const float* w, const float* b, void* y, float* mean, float* rstd,
+                      int rows, int D, float eps, hipStream_t stream) {
+    PPF_CHECK_ARG(rows > 0 && D > 0 && (D % 2) == 0 && D <= 128 * MAXJ, PPF_ERR_SHAPE, "ppf_layernorm_fwd: bad shape rows=%d D=%d", rows, D);
+    const int grid = min((rows + WAVES - 1) / WAVES, 256 * 16);
+    return dispatch_nj(D, [&](auto nj) {
+        hipLaunchKernelGGL((ln_fwd_kernel<decltype(nj)::value>), dim3(grid), dim3(256), 0, stream, x, row_map, w, b, (bf16_t*)y, mean, rstd, rows, D, eps);
+        PPF_LAUNCH_CHECK();
+        return 0;
+    });
+}
+
+int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const float* w, const float* mean, const float* rstd,
+                      const float* dres_in, float* dx_out, float* dw, float* db, void* cast_out, const float* rowscale,
+                      int rows_per_group, const float* colscale, float* dbias_next, const void* branch, float* dcolscale,
+                      int rows, int D, hipStream_t stream) {
+    PPF_CHECK_ARG(rows > 0 && D > 0 && (D % 2) == 0 && D <= 128 * MAXJ, PPF_ERR_SHAPE, "ppf_layernorm_bwd: bad shape rows=%d D=%d", rows, D);
+    PPF_CHECK_ARG(dy != nullptr || dres_in != nullptr, PPF_ERR_ARG, "ppf_layernorm_bwd: need dy or dres_in");
+    LnBwdParams p;
+    p.dy = (const bf16_t*)dy; p.x = x; p.row_map = row_map; p.w = w; p.mean = mean; p.rstd = rstd; p.dres_in = dres_in; p.dx_out = dx_out;
+    p.dw = dw; p.db = db; p.cast_out = (bf16_t*)cast_out; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+    p.colscale = colscale; p.dbias_next = dbias_next; p.branch = (const bf16_t*)branch; p.dcolscale = dcolscale; p.rows = rows; p.D = D;
+    const int grid = min((rows + WAVES * 8 - 1) / (WAVES * 8), 2048);      // >= 8 rows per wave: amortise the column atomics
+    return dispatch_nj(D, [&](auto nj) {
+        hipLaunchKernelGGL((ln_bwd_kernel<decltype(nj)::value>), dim3(grid), dim3(256), 0, stream, p);
+        PPF_LAUNCH_CHECK();
+        return 0;
+    });
+}
+
+}  // extern "C"

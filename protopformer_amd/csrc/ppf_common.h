@@ -35,14 +35,15 @@ extern "C" void ppf_set_error(const char* fmt, ...);
     } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {               // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16 (round-to-nearest-even): native conversion, lowers to v_cvt_pk_bf16_f32 on gfx950 (branch-free)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float2 unpack_bf16x2(uint32_t v) {
     return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u));

@@ -33,3 +33,82 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
               bias, res, res.shape[-1] if res is not None else 0, rowscale, rows_per_group, colscale, aux_in, aux_out, ldaux,
               colsum, float(alpha))
     return out
+
+
+def layernorm_fwd(x, w, b, eps=1e-6, row_map=None):
+    """x fp32 [R, D] -> (y bf16 [rows, D], mean, rstd); rows = len(row_map) gathers source rows."""
+    _chk(x, torch.float32)
+    D = x.shape[-1]
+    rows = row_map.numel() if row_map is not None else x.numel() // D
+    y = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.call("ppf_layernorm_fwd", x, row_map, w, b, y, mean, rstd, rows, D, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, *, dres_in=None, dx_out=None, row_map=None, cast_out=None, rowscale=None,
+                  rows_per_group=1, colscale=None, dbias_next=None, branch=None, dcolscale=None):
+    """dx_out[src] = dres_in[src] + LN'(dy); dw/db accumulate (+=). dy=None: pure scale/cast/colsum pass."""
+    D = x.shape[-1] if x is not None else dres_in.shape[-1]
+    if dy is not None:
+        rows = dy.numel() // D
+    else:
+        rows = dres_in.numel() // D
+    _lib.call("ppf_layernorm_bwd", dy, x, row_map, w, mean, rstd, dres_in, dx_out, dw, db, cast_out, rowscale, rows_per_group,
+              colscale, dbias_next, branch, dcolscale, rows, D)
+
+
+def cast_bf16(src, dst=None):
+    _chk(src, torch.float32)
+    n = src.numel()
+    assert n % 8 == 0
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    _lib.call("ppf_cast_f32_bf16", src, dst, n)
+    return dst
+
+
+def im2col_patch(img, patch):
+    _chk(img, torch.float32)
+    B, C, H, W = img.shape
+    cols = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), dtype=torch.bfloat16, device=img.device)
+    _lib.call("ppf_im2col_patch", img, cols, B, C, H, W, patch)
+    return cols
+
+
+def assemble_tokens(tok, cls, pos, B, Np, D, lead):
+    x = torch.empty((B, Np + lead, D), dtype=torch.float32, device=tok.device)
+    _lib.call("ppf_assemble_tokens", tok, cls, pos, x, B, Np, D, lead)
+    return x
+
+
+def assemble_tokens_bwd(dx, dpos, dcls, B, Np, D, lead):
+    dtok = torch.empty((B * Np, D), dtype=torch.bfloat16, device=dx.device)
+    _lib.call("ppf_assemble_tokens_bwd", dx, dtok, dpos, dcls, B, Np, D, lead)
+    return dtok
+
+
+def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True):
+    """qkv bf16 [B*N, 3D] -> (out bf16 [B*N, D], rowmax, zinv [B,H,N])."""
+    _chk(qkv, torch.bfloat16)
+    out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
+    rowmax = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    zinv = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_attn_fwd", qkv, out, policy, rowmax, zinv, B, H, N, D, int(self_keep))
+    return out, rowmax, zinv
+
+
+def attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=None, self_keep=True, out=None):
+    NP = (N + 3) // 4 * 4
+    if out is None:
+        out = torch.empty((B, N, NP), dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_attn_headmean", qkv, policy, rowmax, zinv, out, NP, B, H, N, D, int(self_keep))
+    return out
+
+
+def attn_bwd(qkv, out, dout, rowmax, zinv, B, H, N, D, policy=None, self_keep=True):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_attn_bwd", qkv, out, dout, dqkv, policy, rowmax, zinv, delta, B, H, N, D, int(self_keep))
+    return dqkv

@@ -1,0 +1,85 @@
+"""GPU parity of the attention kernels vs the CPU oracle (oracle/ppf_oracle.py) on the same bf16-rounded q/k/v."""
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import ppf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _qkv(B, N, D, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(B * N, 3 * D, generator=g)).bfloat16()
+
+
+def _oracle_attn(qkv, B, H, N, D, policy, self_keep):
+    hd = D // H
+    t = qkv.float().reshape(B, N, 3, H, hd)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    p = O.policy_softmax(s, policy, self_keep=self_keep)
+    return (p @ v).transpose(1, 2).reshape(B * N, D), p, (q, k, v)
+
+
+def _policy(B, N, keep, seed):
+    g = torch.Generator().manual_seed(seed)
+    pol = torch.zeros(B, N)
+    pol[:, 0] = 1
+    for b in range(B):
+        pol[b, torch.randperm(N - 1, generator=g)[:keep] + 1] = 1
+    return pol
+
+
+@pytest.mark.parametrize("B,H,N,D,use_policy", [(2, 6, 197, 384, False), (3, 3, 197, 192, True), (2, 4, 196, 192, False),
+                                                (4, 2, 17, 128, True), (2, 2, 65, 96, True)])
+def test_attn_fwd_and_headmean(B, H, N, D, use_policy):
+    from protopformer_amd import ops
+    qkv = _qkv(B, N, D, 3, 1.5)
+    pol = _policy(B, N, max(2, N // 3), 5) if use_policy else torch.ones(B, N)
+    ref_o, ref_p, _ = _oracle_attn(qkv, B, H, N, D, pol, True)
+    pol_d = pol.cuda() if use_policy else None
+    out, rowmax, zinv = ops.attn_fwd(qkv.cuda(), B, H, N, D, policy=pol_d)
+    # P is rounded to bf16 before P.V (fp32 accumulate), output stored in bf16: tolerance = bf16 rounding
+    assert_close(out.float(), ref_o, rtol=1e-2, atol=1e-2, what="attention out")
+    hm = ops.attn_headmean(qkv.cuda(), rowmax, zinv, B, H, N, D, policy=pol_d)
+    assert_close(hm[:, :, :N], ref_p.mean(1), rtol=1e-3, atol=1e-6, what="head-mean probabilities")     # fp32 path
+    if hm.shape[-1] > N:
+        assert float(hm[:, :, N:].abs().max()) == 0.0
+
+
+def test_attn_masked_rows_known_answer():
+    """Policy keeping only cls: every query's mass sits on {cls, itself}."""
+    from protopformer_amd import ops
+    B, H, N, D = 1, 2, 40, 128
+    qkv = _qkv(B, N, D, 9)
+    pol = torch.zeros(B, N); pol[:, 0] = 1
+    out, rowmax, zinv = ops.attn_fwd(qkv.cuda(), B, H, N, D, policy=pol.cuda())
+    hm = ops.attn_headmean(qkv.cuda(), rowmax, zinv, B, H, N, D, policy=pol.cuda())[0, :, :N].cpu()
+    mass = hm[:, 0] + torch.diagonal(hm)
+    mass[0] = hm[0, 0]
+    # (e + eps/N)/(sum + eps): when the unmasked scores sit far below the row max, eps shows up at ~eps/e
+    assert float((mass - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,N,D,use_policy", [(2, 6, 197, 384, False), (2, 3, 197, 192, True), (2, 4, 196, 192, False), (2, 2, 17, 128, True)])
+def test_attn_bwd(B, H, N, D, use_policy):
+    from protopformer_amd import ops
+    hd = D // H
+    qkv = _qkv(B, N, D, 11, 1.2)
+    g = torch.Generator().manual_seed(12)
+    dout = torch.randn(B * N, D, generator=g).bfloat16()
+    pol = _policy(B, N, max(2, N // 3), 5) if use_policy else torch.ones(B, N)
+    x = qkv.float().clone().requires_grad_(True)
+    t = x.reshape(B, N, 3, H, hd)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    p = O.policy_softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, pol, self_keep=True)
+    o = (p @ v).transpose(1, 2).reshape(B * N, D)
+    o.backward(dout.float())
+    ref = x.grad
+    pol_d = pol.cuda() if use_policy else None
+    out, rowmax, zinv = ops.attn_fwd(qkv.cuda(), B, H, N, D, policy=pol_d)
+    dqkv = ops.attn_bwd(qkv.cuda(), out, dout.cuda(), rowmax, zinv, B, H, N, D, policy=pol_d).float().cpu()
+    scale = float(ref.abs().max())
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert_close(dqkv[:, sl], ref[:, sl], rtol=2e-2, atol=1.5e-2 * scale, what=name)   # bf16 P/dS operands + bf16 output
