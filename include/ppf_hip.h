@@ -1,0 +1,125 @@
+/* ppf_hip.h -- C ABI of the MI355X (gfx950) ProtoPFormer hot-path library (protopformer_amd/lib/libppf_hip.so).
+ *
+ * The reference (zju-vipa/ProtoPFormer) has no native/FFI layer: its hot path is Python calling ATen.  This header is
+ * the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md): one entry point per fused operation, each
+ * citing the reference lines it replaces (paths relative to the reference repo; deit = tools/deit_models_attn.py,
+ * cait = tools/cait_models_attn.py).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + explicit sizes/strides; no torch types.  "bf16" buffers are uint16_t storage.
+ *   - every function enqueues work on `stream` and returns immediately (asynchronous w.r.t. the host).
+ *   - the caller owns all memory; the library keeps no pointers after return and allocates nothing persistent.
+ *   - return 0 on success, <0 for invalid shape/alignment/argument (PPF_ERR_*), >0 = hipError_t of a failed launch;
+ *     ppf_last_error() returns a thread-local message.  No exceptions cross the boundary.
+ *   - one host thread per process drives one GPU (data parallel = one process per GPU); re-entrant across streams.
+ */
+#ifndef PPF_HIP_H
+#define PPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
+
+#define PPF_ERR_SHAPE (-1)
+#define PPF_ERR_ALIGN (-2)
+#define PPF_ERR_ARG (-3)
+
+/* ---- runtime ------------------------------------------------------------------------------------------------- */
+const char* ppf_last_error(void);
+int ppf_abi_version(void);
+int ppf_device_info(int* cu_count, int* clock_mhz, char* name, int name_len);
+
+/* ---- dense bf16 MFMA GEMM family: every nn.Linear / 1x1 conv / PatchEmbed conv of the path ----------------------
+ * C[m][n] (+)= epi( sum_kc A(m,kc) * B(n,kc) ), fp32 accumulate.
+ *   trans_a = 0: A[m*lda + kc]      trans_a = 1: A[kc*lda + m]        (same for B with ldb / n)
+ *   forward  y = x W^T + b                (0,0)  deit:47,58 (qkv, proj), timm Mlp fc1/fc2 (deit:80), PatchEmbed (deit:174),
+ *                                                add_on_layers 1x1 conv (protopformer.py:111-114,171-172)
+ *   dgrad    dx = dy W                    (0,1)  autograd of the above
+ *   wgrad    dW += dy^T x (+ db)          (1,1)  split over kc, fp32 atomics into C, colsum[m] += sum_kc A(m,kc)
+ * epi: 0 bf16 out | 1 f32 out | 2 bias+GELU(erf): C=gelu bf16, aux_out=pre-activation bf16 | 3 sigmoid f32 out |
+ *      4 residual: C f32 = res + rowscale[m/rows_per_group]*colscale[n]*(acc+bias)  (DropPath deit:79-80, LayerScale
+ *        cait:156-157), optional aux_out = raw branch output bf16 | 5 dGELU: C bf16 = acc * gelu'(aux_in) | 6 atomic f32. */
+int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                  int trans_b, int epi, const float* bias, const float* res, int ldres, const float* rowscale,
+                  int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,
+                  float alpha, ppf_stream_t stream);
+
+/* ---- LayerNorm (deit:67,72,238 norm1/norm2/norm, eps 1e-6) ----------------------------------------------------
+ * fwd: y bf16 [rows][D] = LN(x fp32 [row_map ? row_map[r] : r][D]); saves mean / rstd per output row.
+ * bwd: dx_out[src] = dres_in[src] + LN'(dy); dw/db accumulate.  Optional fused pass for the residual branch below:
+ *      cast_out = bf16(rowscale*colscale*dx_out), dbias_next += its column sums, dcolscale += sum(rowscale*dx_out*branch).
+ *      dy == NULL: only the fused pass over dres_in. */
+int ppf_layernorm_fwd(const float* x, const int* row_map, const float* w, const float* b, void* y, float* mean, float* rstd,
+                      int rows, int D, float eps, ppf_stream_t stream);
+int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const float* w, const float* mean, const float* rstd,
+                      const float* dres_in, float* dx_out, float* dw, float* db, void* cast_out, const float* rowscale,
+                      int rows_per_group, const float* colscale, float* dbias_next, const void* branch, float* dcolscale,
+                      int rows, int D, ppf_stream_t stream);
+
+/* ---- attention with the policy softmax (deit:29-60; class attention cait:50-90 with self_keep = 0) -------------
+ * qkv bf16 [B*N][3D] packed q|k|v, head h at columns h*hd.  policy [B][N] in {0,1} or NULL.
+ * fwd saves rowmax and 1/(sum+eps) [B][H][N]; headmean = mean over heads of the probabilities, [B][N][NP] fp32
+ * (the rollout input, deit:104 `attn.mean(axis=1)`), recomputed from those statistics. */
+int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, int B, int H, int N, int D,
+                 int self_keep, ppf_stream_t stream);
+int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax, const float* zinv, float* headmean, int NP,
+                      int B, int H, int N, int D, int self_keep, ppf_stream_t stream);
+int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, const float* policy, const float* rowmax,
+                 const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, ppf_stream_t stream);
+
+/* ---- attention rollout + token reservation (deit:99-124, 223-234; cait:223-261, 328-339) ------------------------
+ * hm [L][B][N][NP] head-mean attention of the rollout layers; kdrop = int(N*N*0.9), kdrop_init = int((N+1)*0.9).
+ * lead = 1 (DeiT): row 0 of a_{L-1}..a_0, outputs skip the cls column; lead = 0 (CaiT): init_rows [n_init][B][N+1] are the
+ * class-attention rows.  Outputs: cls_attn [B][N-lead], idx [B][k] int32 ascending (topk + sort), policy [B][N-lead+1]. */
+int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int NP, const float* init_rows, int n_init, int lead,
+                int kdrop, int kdrop_init, float identity, int k, float* cls_attn, int* idx, float* policy, ppf_stream_t stream);
+/* topk(k) + ascending sort of indices on given scores [B][n] (protopformer.py:157-158, 273-274) */
+int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, ppf_stream_t stream);
+
+/* ---- prototype layer (protopformer.py:201-247): squared L2 distances, log similarity, max-pool -------------------
+ * sample b's token i is at tok + b*stride_b + (t0+i)*Dp (fp32); T tokens per sample (T == 1: global / cls branch).
+ * act_kind 0: log((d+1)/(d+eps)), 1: -d.  Outputs act_max [B][P], argmax [B][P], optional dist_full/act_full [B][P][T]. */
+int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
+                  float eps, float* act_max, int* argmax, float* dist_full, float* act_full, ppf_stream_t stream);
+int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
+                  float eps, const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok,
+                  int64_t dstride_b, float* dprotos, ppf_stream_t stream);
+
+/* ---- losses and the frozen class-connection head ------------------------------------------------------------------
+ * PPC loss (protopformer.py:249-288): loss[0] = cov term, loss[1] = mean term; gcov/gmean [B][ppc][T] analytic grads. */
+int ppf_ppc_loss(const float* act, const int* idx, const void* label_i64, int B, int P, int T, int ppc, int side,
+                 float cov_thresh, float mean_thresh, float* partial, float* gcov, float* gmean, float* loss, ppf_stream_t stream);
+int ppf_ppc_loss_bwd(const float* gcov, const float* gmean, const float* up_cov, const float* up_mean, const void* label_i64,
+                     float* g_full, int B, int P, int T, int ppc, ppf_stream_t stream);
+/* nn.CrossEntropyLoss (main.py:390): mean loss + d/dlogits */
+int ppf_cross_entropy(const float* logits, const void* label_i64, float* per_sample, float* dlogits, float* loss, int B, int C,
+                      ppf_stream_t stream);
+/* last_layer / last_layer_global (protopformer.py:126-131, 314-316): C = alpha * A B^T + beta * C, arbitrary strides */
+int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk,
+              int ldc, float alpha, float beta, ppf_stream_t stream);
+int ppf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, ppf_stream_t stream);
+
+/* ---- streaming kernels -------------------------------------------------------------------------------------------- */
+int ppf_cast_f32_bf16(const float* in, void* out, int64_t n, ppf_stream_t stream);
+/* PatchEmbed unfold (timm PatchEmbed conv k=s=patch, deit:174): img [B][C][H][W] -> cols bf16 [B*gh*gw][C*p*p] */
+int ppf_im2col_patch(const float* img, void* cols, int B, int C, int H, int W, int patch, ppf_stream_t stream);
+/* cls token + position embedding (deit:176-178 lead=1; cait:307-309 lead=0) and its backward */
+int ppf_assemble_tokens(const float* tok, const float* cls, const float* pos, float* x, int B, int Np, int D, int lead,
+                        ppf_stream_t stream);
+int ppf_assemble_tokens_bwd(const float* dx, void* dtok, float* dpos, float* dcls, int B, int Np, int D, int lead,
+                            ppf_stream_t stream);
+/* backward of the add-on Sigmoid (protopformer.py:113): dz = bf16(df*f*(1-f)), dbias += column sums */
+int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int rows, int cols, ppf_stream_t stream);
+/* fused AdamW (+EMA, +bf16 re-cast) over flat buffers (tools/create_optimizer.py:92, engine_proto.py:80-81) */
+int ppf_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
+                   const int64_t* seg_bounds, const float* seg_lr, const float* seg_wd, float beta1, float beta2, float eps,
+                   int step, float ema_decay, float grad_scale, ppf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPF_HIP_H */

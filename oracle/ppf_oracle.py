@@ -152,7 +152,7 @@ def topk_sorted(scores: Tensor, k: int) -> Tensor:
 
 def deit_features(sd: SD, img: Tensor, heads: int, depth: int, reserve_layer: int, reserve_k: int,
                   droppath: Optional[List[Tuple[Optional[Tensor], Optional[Tensor]]]] = None,
-                  pre: str = "features.", return_probs: bool = False):
+                  pre: str = "features.", return_probs: bool = False, force_idx: Optional[Tensor] = None):
     """forward_feature_patch_embed_all + forward_feature_mask_train_direct (deit:172-181, 209-240).
 
     Returns x (B,1+Np,D) after the final norm, cls_token_attn (B,Np) and the reserved indices (B,k)."""
@@ -167,7 +167,8 @@ def deit_features(sd: SD, img: Tensor, heads: int, depth: int, reserve_layer: in
         if i == reserve_layer:
             R = deit_rollout([p.detach() for p in probs[:i]])
             cls_attn = R[:, 0, 1:]
-            idx = topk_sorted(cls_attn, reserve_k)
+            # force_idx (tests only): follow a given token reservation, e.g. the one a bf16 run selected
+            idx = topk_sorted(cls_attn, reserve_k) if force_idx is None else force_idx
             policy = torch.zeros(B, N)
             policy[:, 0] = 1.0
             policy.scatter_(1, idx + 1, 1.0)
@@ -248,7 +249,8 @@ def cait_rollout(sa_probs: Sequence[Tensor], ca_probs: Sequence[Tensor]) -> Tens
 
 def cait_features(sd: SD, img: Tensor, heads: int, depth: int, reserve_layer: int, reserve_k: int,
                   droppath: Optional[List[Tuple[Optional[Tensor], Optional[Tensor]]]] = None,
-                  depth_token_only: int = 2, pre: str = "features.", return_probs: bool = False):
+                  depth_token_only: int = 2, pre: str = "features.", return_probs: bool = False,
+                  force_idx: Optional[Tensor] = None):
     """forward_feature_patch_embed_all + forward_feature_mask_train_direct (cait:303-345)."""
     B = img.shape[0]
     x = patch_embed(sd, img, pre) + sd[pre + "pos_embed"]
@@ -267,7 +269,7 @@ def cait_features(sd: SD, img: Tensor, heads: int, depth: int, reserve_layer: in
             # the reference's slice [depth:] of all_attn holds the CA rows produced so far (cait:328,249)
             res = cait_rollout([p.detach() for p in sa_probs], [p.detach() for p in ca_probs])
             cls_attn = res[:, 0]
-            idx = topk_sorted(cls_attn, reserve_k)
+            idx = topk_sorted(cls_attn, reserve_k) if force_idx is None else force_idx
             policy = torch.zeros(B, 1 + Np)
             policy[:, 0] = 1.0
             policy.scatter_(1, idx + 1, 1.0)
@@ -312,12 +314,13 @@ def proto_activations(tokens: Tensor, protos: Tensor, activation: str = "log") -
 
 
 def ppnet_forward(sd: SD, img: Tensor, cfg: dict, train: bool = True,
-                  droppath: Optional[list] = None) -> dict:
+                  droppath: Optional[list] = None, force_idx: Optional[Tensor] = None) -> dict:
     """PPNet.forward (protopformer.py:290-335) for either backbone.
 
     cfg keys: arch ('deit'|'cait'), heads, depth, reserve_layer, reserve_k, global_coe."""
     feats = deit_features if cfg["arch"] == "deit" else cait_features
-    x, cls_attn, idx = feats(sd, img, cfg["heads"], cfg["depth"], cfg["reserve_layer"], cfg["reserve_k"], droppath)
+    x, cls_attn, idx = feats(sd, img, cfg["heads"], cfg["depth"], cfg["reserve_layer"], cfg["reserve_k"], droppath,
+                             force_idx=force_idx)
     B, _, D = x.shape
     cls_tok = x[:, :1]
     img_tok = torch.gather(x[:, 1:], 1, idx[:, :, None].expand(-1, -1, D))        # protopformer.py:156-162
@@ -358,7 +361,7 @@ def weighted_grid_moments(weights: Tensor, side: int) -> Tuple[Tensor, Tensor]:
 
 
 def ppc_loss(total_proto_act: Tensor, cls_attn_rollout: Tensor, original_fea_len: int, label: Tensor,
-             protos_per_class: int, cov_thresh: float, mean_thresh: float) -> Tuple[Tensor, Tensor]:
+             protos_per_class: int, cov_thresh: float, mean_thresh: float, force_idx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """get_PPC_loss (protopformer.py:259-288)."""
     B = total_proto_act.shape[0]
     side = int(original_fea_len ** 0.5)
@@ -366,7 +369,7 @@ def ppc_loss(total_proto_act: Tensor, cls_attn_rollout: Tensor, original_fea_len
     k = act.shape[-1]
     cols = label.reshape(B, 1) * protos_per_class + torch.arange(protos_per_class).reshape(1, -1)
     own = torch.gather(act, 1, cols[:, :, None].expand(-1, -1, k))     # (B,ppc,k)
-    idx = topk_sorted(cls_attn_rollout, k)
+    idx = topk_sorted(cls_attn_rollout, k) if force_idx is None else force_idx
     canvas = torch.zeros(B, protos_per_class, original_fea_len)
     canvas = canvas.scatter(2, idx[:, None, :].expand(-1, protos_per_class, -1), own)
     mean, cov = weighted_grid_moments(canvas.reshape(B * protos_per_class, -1), side)
@@ -390,7 +393,8 @@ def train_loss(out: dict, label: Tensor, cfg: dict, with_ppc: bool = True) -> Tu
     loss = ce
     if with_ppc:
         cov, mean = ppc_loss(out["total_proto_act"], out["cls_token_attn"], out["cls_token_attn"].shape[-1], label,
-                             cfg["protos_per_class"], cfg.get("ppc_cov_thresh", 1.0), cfg.get("ppc_mean_thresh", 2.0))
+                             cfg["protos_per_class"], cfg.get("ppc_cov_thresh", 1.0), cfg.get("ppc_mean_thresh", 2.0),
+                             force_idx=out["reserve_idx"])
         parts.update(ppc_cov=cov, ppc_mean=mean)
         loss = loss + cfg.get("ppc_cov_coe", 0.1) * cov + cfg.get("ppc_mean_coe", 0.5) * mean
     return loss, parts

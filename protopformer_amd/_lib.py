@@ -23,6 +23,16 @@ SIGS = {
     "ppf_attn_fwd": "ppppp" "iiiii" "s",
     "ppf_attn_headmean": "ppppp" "i" "iiiii" "s",
     "ppf_attn_bwd": "pppppppp" "iiiii" "s",
+    "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "ppp" "s",
+    "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
+    "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "s",
+    "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
+    "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",
+    "ppf_cross_entropy": "ppppp" "ii" "s",
+    "ppf_sgemm": "ppp" "iii" "llll" "i" "ff" "s",
+    "ppf_axpby": "ppp" "ff" "l" "s",
+    "ppf_topk_sorted": "piiips",
+    "ppf_sigmoid_bwd": "ppppiis",
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "s": ctypes.c_void_p}

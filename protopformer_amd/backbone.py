@@ -1,0 +1,209 @@
+"""Forward / backward orchestration of the backbone on the HIP kernels (host-side launch sequencing only).
+
+The whole "image -> reserved, add-on-projected tokens" stage is ONE autograd node (TokensFn) whose backward is the
+hand-written kernel sequence below; weight gradients are accumulated by the kernels straight into the flat gradient
+buffer (param.grad views), so the node returns no parameter gradients to autograd.
+Reference call path: protopformer.py:141-173 (conv_features) -> deit:172-181, 209-240.
+"""
+import torch
+
+from . import ops
+from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, EPI_SIGMOID_F32
+
+LN_EPS = 1e-6
+
+
+def droppath_scales(rates, B, device, training):
+    """Per-layer, per-sample DropPath factors floor(keep + U)/keep (timm DropPath); None where the rate is 0.
+    Returns (scales [n_active, B] tensor or None, index map layer-slot -> row or -1)."""
+    slots = [r if training else 0.0 for r in rates]
+    active = [i for i, r in enumerate(slots) if r > 0.0]
+    if not active:
+        return None, [-1] * len(slots)
+    keep = torch.tensor([1.0 - slots[i] for i in active], device=device, dtype=torch.float32)[:, None]
+    u = torch.rand(len(active), B, device=device, dtype=torch.float32)
+    scales = (torch.floor(keep + u) / keep).contiguous()
+    index = [-1] * len(slots)
+    for row, i in enumerate(active):
+        index[i] = row
+    return scales, index
+
+
+def _dp(dp, slot):
+    if dp is None:
+        return None
+    scales, index = dp
+    return None if scales is None or index[slot] < 0 else scales[index[slot]]
+
+
+# ------------------------------------------------------------------------------------------------ DeiT forward
+def deit_embed(feats, store, img, saved=None):
+    """PatchEmbed (im2col + GEMM) + cls token + position embedding (deit:172-181). Returns x fp32 [B, 1+Np, D]."""
+    pe = feats.patch_embed
+    B = img.shape[0]
+    D, Np = feats.embed_dim, pe.num_patches
+    cols = ops.im2col_patch(img.contiguous().float(), pe.patch_size)
+    w16 = store.w16(pe.proj.weight).reshape(D, -1)
+    tok = ops.gemm(cols, w16, epi=EPI_F32, bias=pe.proj.bias)
+    x = ops.assemble_tokens(tok, feats.cls_token, feats.pos_embed, B, Np, D, 1)
+    if saved is not None:
+        saved["cols"] = cols
+    return x
+
+
+def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
+    """The 12 blocks with attention rollout + token reservation at `reserve_layer` (deit:209-236).
+    x fp32 [B,N,D] -> (x_out, cls_token_attn [B,N-1], idx int32 [B,k], per-layer saved activations)."""
+    B, N, D = x.shape
+    H = feats.num_heads
+    M = B * N
+    NP = (N + 3) // 4 * 4
+    hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
+    policy = None
+    cls_attn = idx = None
+    layers = []
+    x = x.reshape(M, D)
+    for i, blk in enumerate(feats.blocks):
+        if i == reserve_layer:
+            cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1)
+        n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
+        ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, N, D, policy=policy, self_keep=True)
+        if i < reserve_layer:
+            ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
+        s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
+        x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N)
+        n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
+        g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
+        x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=N)
+        if save:
+            layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ao=ao, rowmax=rowmax, zinv=zinv, x1=x1, n2=n2,
+                               mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2))
+        x = x2
+    return x.reshape(B, N, D), cls_attn, idx, layers
+
+
+def gather_rows_map(idx, N):
+    """Source-row map of the reserved tokens: per sample [cls, 1+idx...] as flat rows of the [B*N] token matrix
+    (integer index plumbing of protopformer.py:156-162)."""
+    B, k = idx.shape
+    base = torch.arange(B, device=idx.device, dtype=torch.int32)[:, None] * N
+    rows = torch.cat([base, base + 1 + idx], dim=1)
+    return rows.reshape(-1).contiguous()
+
+
+def head_tokens_fwd(ppnet, store, x, idx):
+    """Final norm on the reserved rows only + add-on 1x1 conv + sigmoid (deit:238; protopformer.py:162-172).
+    Returns f fp32 [B, 1+k, Dp] (token 0 = cls) and what backward needs."""
+    feats = ppnet.features
+    B, N, D = x.shape
+    k = idx.shape[1]
+    row_map = gather_rows_map(idx, N)
+    nf, meanf, rstdf = ops.layernorm_fwd(x.reshape(B * N, D), feats.norm.weight, feats.norm.bias, LN_EPS, row_map=row_map)
+    conv = ppnet.add_on_layers[0]
+    Dp = conv.out_channels
+    f = ops.gemm(nf, store.w16(conv.weight).reshape(Dp, D), epi=EPI_SIGMOID_F32, bias=conv.bias)
+    return f.reshape(B, 1 + k, Dp), dict(row_map=row_map, nf=nf, meanf=meanf, rstdf=rstdf)
+
+
+# ------------------------------------------------------------------------------------------------ DeiT backward
+def _wgrad(store, dy16, x16, weight, bias=None):
+    """dW[N,K] += dy^T x (split-K fp32 atomics into the flat grad), optional fused bias grad (column sums of dy)."""
+    gw = store.grad_view(weight)
+    ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
+             colsum=store.grad_view(bias) if bias is not None else None)
+
+
+def deit_backward(ppnet, store, saved, df):
+    """Backward of image -> f. df: fp32 [B*(1+k), Dp] gradient w.r.t. the sigmoid outputs."""
+    feats = ppnet.features
+    layers, head = saved["layers"], saved["head"]
+    x_last = saved["x_last"]                      # [B, N, D] fp32 (pre-final-norm)
+    B, N, D = x_last.shape
+    M = B * N
+    dev = x_last.device
+    conv = ppnet.add_on_layers[0]
+    Dp = conv.out_channels
+    # add-on: sigmoid' then the two GEMMs
+    dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), store.grad_view(conv.bias))
+    _wgrad(store, dz, head["nf"], conv.weight)
+    dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
+    # final norm backward scatters into the (zero) residual-stream gradient; also emits the bf16 gradient of the last fc2
+    dx = torch.zeros((M, D), dtype=torch.float32, device=dev)
+    dyb = torch.zeros((M, D), dtype=torch.bfloat16, device=dev)
+    last = feats.blocks[-1]
+    ops.layernorm_bwd(dnf, x_last.reshape(M, D), feats.norm.weight, head["meanf"], head["rstdf"], store.grad_view(feats.norm.weight),
+                      store.grad_view(feats.norm.bias), dx_out=dx, row_map=head["row_map"], cast_out=dyb, rowscale=layers[-1]["s2"],
+                      rows_per_group=N, dbias_next=store.grad_view(last.mlp.fc2.bias))
+    gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
+    if gs is not None:
+        gs.chunk_ready(gs.tail_chunk)
+    for i in range(len(layers) - 1, -1, -1):
+        L, blk = layers[i], feats.blocks[i]
+        # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
+        _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight)
+        dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
+        _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+        dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
+        ops.layernorm_bwd(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
+                          store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=N,
+                          dbias_next=store.grad_view(blk.attn.proj.bias))
+        # attention branch: x1 = x + s1 * (attn(n1) Wp^T + bp)
+        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
+        dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
+        dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, N, D, policy=L["policy"], self_keep=True)
+        _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
+        dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
+        if i > 0:
+            prev = feats.blocks[i - 1]
+            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
+                              store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
+                              rows_per_group=N, dbias_next=store.grad_view(prev.mlp.fc2.bias))
+        else:
+            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
+                              store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
+        if gs is not None and i in gs.block_chunk:
+            gs.chunk_ready(gs.block_chunk[i])
+    # token assembly + patch embedding
+    pe = feats.patch_embed
+    Np = pe.num_patches
+    dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(N, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
+    _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
+    if gs is not None:
+        gs.chunk_ready(gs.head_chunk)
+
+
+class TokensFn(torch.autograd.Function):
+    """image -> (f [B,1+k,Dp], cls_token_attn [B,Np], reserve idx [B,k]); parameters enter only to hook autograd."""
+
+    @staticmethod
+    def forward(ctx, img, ppnet, dp, *params):
+        store = ppnet.flat_store()
+        store.refresh_bf16()
+        feats = ppnet.features
+        need_bwd = any(ctx.needs_input_grad)
+        saved = {} if need_bwd else None
+        (layer, k), = ppnet.reserve_layer_nums
+        fwd = ppnet._arch_fns
+        x = fwd["embed"](feats, store, img, saved)
+        x_out, cls_attn, idx, layers = fwd["blocks"](feats, store, x, layer, k, dp, save=need_bwd)
+        f, head = head_tokens_fwd(ppnet, store, x_out, idx)
+        if need_bwd:
+            saved.update(layers=layers, head=head, x_last=x_out, f=f)
+            ctx.saved = saved
+            ctx.ppnet = ppnet
+        ctx.mark_non_differentiable(cls_attn, idx)
+        return f, cls_attn, idx
+
+    @staticmethod
+    def backward(ctx, df, _dcls, _didx):
+        ppnet, saved = ctx.ppnet, ctx.saved
+        store = ppnet.flat_store()
+        store.attach_all_grads()
+        ppnet._arch_fns["backward"](ppnet, store, saved, df.contiguous().reshape(-1, df.shape[-1]))
+        ctx.saved = None
+        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+DEIT_FNS = dict(embed=deit_embed, blocks=deit_blocks_fwd, backward=deit_backward)

@@ -109,6 +109,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamParams a) {
     }
 }
 
+// dz = bf16(df * f * (1 - f)) for f = sigmoid(z); dbias[c] += column sums of the rounded dz (bias grad of the add-on layer)
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ df, const float* __restrict__ f, bf16_t* __restrict__ dz,
+                                                          float* __restrict__ dbias, int rows, int cols, int rows_per_block) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const size_t o = (size_t)r * cols + c;
+            const float fv = f[o];
+            const bf16_t h = f32_to_bf16(df[o] * fv * (1.0f - fv));
+            dz[o] = h;
+            acc += bf16_to_f32(h);
+        }
+        if (dbias) unsafeAtomicAdd(dbias + c, acc);
+    }
+}
+
 inline int grid_for(int64_t work, int per_block = 256) {
     int64_t g = (work + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -147,6 +164,14 @@ int ppf_assemble_tokens_bwd(const float* dx, void* dtok, float* dpos, float* dcl
     const int bchunk = 16;
     hipLaunchKernelGGL(assemble_bwd_kernel, dim3((threads + 255) / 256, (B + bchunk - 1) / bchunk), dim3(256), 0, stream, dx, (bf16_t*)dtok, dpos, dcls, B,
                        Np, D, lead, bchunk);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int rows, int cols, hipStream_t stream) {
+    PPF_CHECK_ARG(rows > 0 && cols > 0, PPF_ERR_SHAPE, "ppf_sigmoid_bwd: bad shape");
+    const int rpb = 16;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, df, f, (bf16_t*)dz, dbias, rows, cols, rpb);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,234 @@
+// Small fp32 kernels of the classification head and the losses:
+//   * PPC loss (protopformer.py:249-288): weighted grid mean / covariance per (sample, label prototype),
+//     one workgroup per sample, wave-shuffle reductions, analytic gradient emitted alongside the loss
+//   * cross-entropy (main.py:390) with its gradient
+//   * the frozen +1/-0.5 class-connection linears (protopformer.py:126-131,314-316): a plain strided fp32 GEMM
+// All reductions run in a fixed order (per-sample partials + a single-workgroup tree), i.e. deterministic.
+#include "ppf_common.h"
+
+namespace {
+
+constexpr int MAXPPC = 16;
+
+struct PpcParams {
+    const float* act;        // [B][P][T]
+    const int* idx;          // [B][T] ascending patch indices of the reserved tokens
+    const long long* label;  // [B]
+    int B, P, T, ppc, side;
+    float cov_thresh, mean_thresh;
+    float* partial;          // [B][2] per-sample sums of the two hinge terms
+    float* gcov;             // [B][ppc][T]  d(cov_loss)/d(act)
+    float* gmean;            // [B][ppc][T]  d(mean_loss)/d(act)
+};
+
+__global__ __launch_bounds__(256) void ppc_kernel(const PpcParams p) {
+    __shared__ float mu[MAXPPC][2], S[MAXPPC], hinge_cov[MAXPPC], gmu[MAXPPC][2];
+    __shared__ float mean_sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    const int N = p.side * p.side;
+    const float nfac = (float)N / (float)(N - 1);
+    const int lab = (int)p.label[b];
+    const float inv_cnt = 1.0f / ((float)p.B * (float)p.ppc);
+    // pass 1: moments per label prototype (one wave per prototype, lanes over tokens)
+    for (int j = wave; j < p.ppc; j += 4) {
+        const float* w = p.act + ((size_t)b * p.P + (size_t)lab * p.ppc + j) * p.T;
+        float s = 0.f, sx = 0.f, sy = 0.f;
+        for (int t = lane; t < p.T; t += 64) {
+            const int id = p.idx[(size_t)b * p.T + t];
+            const float wt = w[t], x = (float)(id / p.side), y = (float)(id % p.side);
+            s += wt; sx += wt * x; sy += wt * y;
+        }
+        s = wave_sum(s); sx = wave_sum(sx); sy = wave_sum(sy);
+        const float mx = sx / s, my = sy / s;
+        float v = 0.f;
+        for (int t = lane; t < p.T; t += 64) {
+            const int id = p.idx[(size_t)b * p.T + t];
+            const float dx = (float)(id / p.side) - mx, dy = (float)(id % p.side) - my;
+            v += w[t] * (dx * dx + dy * dy);
+        }
+        v = wave_sum(v) / s;                                    // weighted second moment (xx + yy)
+        const float c = 0.5f * nfac * v;                        // (cov00 + cov11) / 2 with the reference's N/(N-1)
+        const bool on = c > p.cov_thresh;
+        for (int t = lane; t < p.T; t += 64) {
+            const int id = p.idx[(size_t)b * p.T + t];
+            const float dx = (float)(id / p.side) - mx, dy = (float)(id % p.side) - my;
+            p.gcov[((size_t)b * p.ppc + j) * p.T + t] = on ? inv_cnt * 0.5f * nfac * ((dx * dx + dy * dy) - v) / s : 0.f;
+        }
+        if (lane == 0) { mu[j][0] = mx; mu[j][1] = my; S[j] = s; hinge_cov[j] = on ? c - p.cov_thresh : 0.f; }
+    }
+    __syncthreads();
+    // pass 2: pairwise mean distances (tiny: ppc x ppc), gradient w.r.t. each mean
+    if (threadIdx.x == 0) {
+        float ms = 0.f;
+        for (int j = 0; j < p.ppc; ++j) { gmu[j][0] = 0.f; gmu[j][1] = 0.f; }
+        const float pair_norm = 1.0f / ((float)p.B * (float)p.ppc * (float)p.ppc);
+        for (int j = 0; j < p.ppc; ++j)
+            for (int k = 0; k < p.ppc; ++k) {
+                if (j == k) continue;
+                const float dx = mu[j][0] - mu[k][0], dy = mu[j][1] - mu[k][1];
+                const float d = sqrtf(dx * dx + dy * dy);
+                if (p.mean_thresh - d > 0.f) {
+                    ms += p.mean_thresh - d;
+                    if (d > 0.f) {      // pair (j,k) and (k,j) both appear in the sum: each contributes -(mu_j-mu_k)/d to j
+                        gmu[j][0] -= 2.0f * pair_norm * dx / d;
+                        gmu[j][1] -= 2.0f * pair_norm * dy / d;
+                    }
+                }
+            }
+        mean_sum = ms;
+        float cs = 0.f;
+        for (int j = 0; j < p.ppc; ++j) cs += hinge_cov[j];
+        p.partial[2 * b] = cs;
+        p.partial[2 * b + 1] = ms;
+    }
+    __syncthreads();
+    for (int j = wave; j < p.ppc; j += 4) {
+        const float mx = mu[j][0], my = mu[j][1], s = S[j], gx = gmu[j][0], gy = gmu[j][1];
+        for (int t = lane; t < p.T; t += 64) {
+            const int id = p.idx[(size_t)b * p.T + t];
+            const float dx = (float)(id / p.side) - mx, dy = (float)(id % p.side) - my;
+            p.gmean[((size_t)b * p.ppc + j) * p.T + t] = (gx * dx + gy * dy) / s;
+        }
+    }
+}
+
+// out[c] = scale[c] * sum_i in[i*stride + c]   (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* in, int n, int stride, int cols, float s0, float s1, float* out) {
+    __shared__ float red[256];
+    for (int c = 0; c < cols; ++c) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s += in[(size_t)i * stride + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = red[0] * (c == 0 ? s0 : s1);
+        __syncthreads();
+    }
+}
+
+// g_full[b][label*ppc + j][t] = up[0]*gcov + up[1]*gmean  (g_full must be zero elsewhere)
+__global__ __launch_bounds__(256) void ppc_bwd_kernel(const float* gcov, const float* gmean, const float* up_cov, const float* up_mean,
+                                                      const long long* label, float* g_full, int B, int P, int T, int ppc) {
+    const int b = blockIdx.x;
+    const float uc = up_cov ? up_cov[0] : 0.f, um = up_mean ? up_mean[0] : 0.f;
+    const int lab = (int)label[b];
+    for (int i = threadIdx.x; i < ppc * T; i += 256) {
+        const int j = i / T, t = i % T;
+        g_full[((size_t)b * P + (size_t)lab * ppc + j) * T + t] = uc * gcov[((size_t)b * ppc + j) * T + t] + um * gmean[((size_t)b * ppc + j) * T + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_kernel(const float* logits, const long long* label, float* per_sample, float* dlogits, int B, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float* row = logits + (size_t)b * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(row[c] - mx);
+    s = wave_sum(s);
+    const int lab = (int)label[b];
+    const float lse = mx + __logf(s);
+    if (lane == 0) per_sample[b] = lse - row[lab];
+    const float invB = 1.0f / (float)B;
+    for (int c = lane; c < C; c += 64) dlogits[(size_t)b * C + c] = (__expf(row[c] - lse) - (c == lab ? 1.0f : 0.0f)) * invB;
+}
+
+// C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m][n]; 32x32 tile, 2x2 per thread
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak,
+                                                    int64_t sbn, int64_t sbk, int ldc, float alpha, float beta) {
+    __shared__ float sa[32][33], sb[32][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            const int r = i >> 5, k = i & 31;
+            sa[r][k] = (m0 + r < M && k0 + k < K) ? A[(size_t)(m0 + r) * sam + (size_t)(k0 + k) * sak] : 0.f;
+            sb[r][k] = (n0 + r < N && k0 + k < K) ? Bm[(size_t)(n0 + r) * sbn + (size_t)(k0 + k) * sbk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = sa[ty][k], a1 = sa[ty + 16][k], b0 = sb[tx][k], b1 = sb[tx + 16][k];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < N) {
+                float* c = C + (size_t)m * ldc + n;
+                *c = alpha * acc[i][j] + (beta != 0.f ? beta * *c : 0.f);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, float a, float b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a * x[i] + b * y[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+// PPC loss. act [B][P][T] (total_proto_act), idx [B][T] int32, label [B] int64.  Writes loss[0] = cov loss,
+// loss[1] = mean loss, and the analytic gradients gcov / gmean [B][ppc][T]; partial is [B][2] scratch.
+int ppf_ppc_loss(const float* act, const int* idx, const void* label, int B, int P, int T, int ppc, int side, float cov_thresh,
+                 float mean_thresh, float* partial, float* gcov, float* gmean, float* loss, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && T > 0 && ppc >= 1 && ppc <= MAXPPC && side >= 2 && P % ppc == 0, PPF_ERR_SHAPE, "ppf_ppc_loss: bad shape");
+    PpcParams p;
+    p.act = act; p.idx = idx; p.label = (const long long*)label; p.B = B; p.P = P; p.T = T; p.ppc = ppc; p.side = side;
+    p.cov_thresh = cov_thresh; p.mean_thresh = mean_thresh; p.partial = partial; p.gcov = gcov; p.gmean = gmean;
+    hipLaunchKernelGGL(ppc_kernel, dim3(B), dim3(256), 0, stream, p);
+    PPF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, stream, partial, B, 2, 2, 1.0f / ((float)B * ppc), 1.0f / ((float)B * ppc * ppc), loss);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Scatter up_cov*gcov + up_mean*gmean into the label rows of g_full [B][P][T] (caller zero-fills g_full).
+int ppf_ppc_loss_bwd(const float* gcov, const float* gmean, const float* up_cov, const float* up_mean, const void* label, float* g_full, int B,
+                     int P, int T, int ppc, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && T > 0 && ppc >= 1, PPF_ERR_SHAPE, "ppf_ppc_loss_bwd: bad shape");
+    hipLaunchKernelGGL(ppc_bwd_kernel, dim3(B), dim3(256), 0, stream, gcov, gmean, up_cov, up_mean, (const long long*)label, g_full, B, P, T, ppc);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Mean cross-entropy over the batch and d(loss)/d(logits); per_sample is [B] scratch.
+int ppf_cross_entropy(const float* logits, const void* label, float* per_sample, float* dlogits, float* loss, int B, int C, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && C > 0, PPF_ERR_SHAPE, "ppf_cross_entropy: bad shape");
+    hipLaunchKernelGGL(ce_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, logits, (const long long*)label, per_sample, dlogits, B, C);
+    PPF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, stream, per_sample, B, 1, 1, 1.0f / (float)B, 0.f, loss);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Small strided fp32 GEMM for the frozen class-connection layers: C = alpha * A B^T + beta * C.
+int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int ldc,
+              float alpha, float beta, hipStream_t stream) {
+    PPF_CHECK_ARG(M > 0 && N > 0 && K > 0, PPF_ERR_SHAPE, "ppf_sgemm: bad shape");
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, stream, A, Bm, C, M, N, K, sam, sak, sbn, sbk, ldc, alpha, beta);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, hipStream_t stream) {
+    PPF_CHECK_ARG(n > 0, PPF_ERR_SHAPE, "ppf_axpby: bad length");
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(axpby_kernel, dim3((int)(g > 1024 ? 1024 : g)), dim3(256), 0, stream, x, y, out, a, b, n);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+// Prototype layer (protopformer.py:201-247): squared-L2 distance of every reserved token to every prototype,
+// log similarity, max-pool over the tokens of a sample -- and its backward.
+//
+// Forward: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for the token.prototype contraction -- the expansion
+// |x|^2 - 2 x.p + |p|^2 cancels catastrophically for close pairs, exactly where log((d+1)/(d+eps)) is steepest,
+// so bf16 operands are not an option here (SURVEY 7 "Distance cancellation").  One workgroup = one sample
+// (all its T tokens, padded to TT*32 rows) x 128 prototypes; |x|^2 and |p|^2 are accumulated from the very
+// operands that feed the MFMA; relu / log / max+argmax over tokens run in registers (token index lives in the
+// accumulator registers, prototype index in the lane).  The full (B,P,T) maps the API returns are transposed
+// through LDS so HBM sees token-contiguous runs.
+//
+// Backward: dL/dd is ~98 % sparse (one arg-max token per (sample, prototype) + the label's prototypes from the
+// PPC loss), so it is a gather-scale-accumulate in exact fp32 on (x - p) differences, deterministic, no atomics:
+//   proto_bwd_tokens : one workgroup per sample, waves own tokens, scan the prototype axis
+//   proto_bwd_protos : one workgroup per prototype, waves own samples, scan the token axis
+#include "ppf_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int PB = 128;           // prototypes per workgroup (4 waves x 32)
+constexpr int BKF = 32;           // contraction chunk (floats)
+constexpr int LDP = BKF + 1;      // padded LDS pitch: conflict-free ds_read_b32 for the MFMA operands
+
+struct ProtoFwdParams {
+    const float* tok;      // token rows: row(b, i) = tok + b*stride_b + (t0 + i)*Dp      (POOL)
+                           //            row(g, i) = tok + (g*rows + i)*stride_b + t0*Dp  (!POOL: one token per sample)
+    int64_t stride_b;
+    int t0, T;             // POOL: tokens per sample
+    const float* protos;   // [P][Dp]
+    int B, P, Dp;
+    int act_kind;          // 0: log((d+1)/(d+eps))   1: -d
+    float eps;
+    float* act_max;        // [B][P]
+    int* argmax;           // [B][P] (POOL only)
+    float* dist_full;      // [B][P][T] or null
+    float* act_full;       // [B][P][T] or null
+};
+
+__device__ __forceinline__ float activation(float d, int kind, float eps) {
+    return kind == 0 ? __logf((d + 1.0f) / (d + eps)) : -d;
+}
+
+template <int TT, bool POOL>
+__global__ __launch_bounds__(256) void proto_fwd_kernel(const ProtoFwdParams p) {
+    constexpr int ROWS = TT * 32;
+    constexpr int STAGE = (ROWS + PB) * LDP;                       // floats
+    constexpr int XPOSE = 4 * 32 * (ROWS + 1);                     // per-wave [32 p][ROWS+1] transpose tiles
+    __shared__ float lds[(STAGE > XPOSE ? STAGE : XPOSE) + ROWS];
+    float* ltok = lds;
+    float* lpro = lds + ROWS * LDP;
+    float* lx2 = lds + (STAGE > XPOSE ? STAGE : XPOSE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int p0 = blockIdx.x * PB, grp = blockIdx.y;
+    const int nrows = POOL ? p.T : min(ROWS, p.B - grp * ROWS);
+
+    f32x16 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float x2p[TT], p2p = 0.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) x2p[t] = 0.f;
+
+    for (int k0 = 0; k0 < p.Dp; k0 += BKF) {
+        __syncthreads();
+        for (int i = tid; i < (ROWS + PB) * (BKF / 4); i += 256) {
+            const int row = i / (BKF / 4), c4 = i % (BKF / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < ROWS) {
+                if (row < nrows && k0 + c4 * 4 < p.Dp) {
+                    const float* src = POOL ? p.tok + (size_t)grp * p.stride_b + (size_t)(p.t0 + row) * p.Dp
+                                            : p.tok + (size_t)(grp * ROWS + row) * p.stride_b + (size_t)p.t0 * p.Dp;
+                    v = *reinterpret_cast<const float4*>(src + k0 + c4 * 4);
+                }
+                float* d = ltok + row * LDP + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            } else {
+                const int pr = row - ROWS;
+                if (p0 + pr < p.P && k0 + c4 * 4 < p.Dp) v = *reinterpret_cast<const float4*>(p.protos + (size_t)(p0 + pr) * p.Dp + k0 + c4 * 4);
+                float* d = lpro + pr * LDP + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < BKF / 2; ++kk) {
+            const float bv = lpro[(wave * 32 + (lane & 31)) * LDP + kk * 2 + hh];
+            p2p += bv * bv;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const float av = ltok[(t * 32 + (lane & 31)) * LDP + kk * 2 + hh];
+                x2p[t] += av * av;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);     // D[i = token][j = prototype]
+            }
+        }
+    }
+    // |p|^2 for this lane's prototype, |x|^2 per token row (wave 0 publishes them)
+    const float p2 = p2p + __shfl_xor(p2p, 32, 64);
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float x2 = x2p[t] + __shfl_xor(x2p[t], 32, 64);
+            if (hh == 0) lx2[t * 32 + lane] = x2;
+        }
+    }
+    __syncthreads();
+    const int pidx = p0 + wave * 32 + (lane & 31);
+    float best = -INFINITY;
+    int besti = 0;
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float d = fmaxf(lx2[row] + (-2.0f * acc[t][r] + p2), 0.0f);      // protopformer.py:213-216 association order
+            acc[t][r] = d;
+            if (POOL && row < p.T) {
+                const float a = activation(d, p.act_kind, p.eps);
+                if (a > best) { best = a; besti = row; }
+            }
+        }
+    if (POOL) {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(besti, 32, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        if (hh == 0 && pidx < p.P) {
+            p.act_max[(size_t)grp * p.P + pidx] = best;
+            p.argmax[(size_t)grp * p.P + pidx] = besti;
+        }
+    } else {
+        // one token per sample: rows are samples, no pooling
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int smp = grp * ROWS + row;
+                if (row < nrows && pidx < p.P) {
+                    p.act_max[(size_t)smp * p.P + pidx] = activation(acc[t][r], p.act_kind, p.eps);
+                    if (p.dist_full) p.dist_full[(size_t)smp * p.P + pidx] = acc[t][r];
+                    if (p.act_full) p.act_full[(size_t)smp * p.P + pidx] = activation(acc[t][r], p.act_kind, p.eps);
+                }
+            }
+        return;
+    }
+    // full maps (B,P,T): transpose the wave's [token][prototype] tile through LDS -> token-contiguous stores
+    float* xp = lds + wave * 32 * (ROWS + 1);
+    for (int pass = 0; pass < 2; ++pass) {
+        float* dst = pass == 0 ? p.dist_full : p.act_full;
+        if (!dst) continue;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                xp[(lane & 31) * (ROWS + 1) + row] = pass == 0 ? acc[t][r] : activation(acc[t][r], p.act_kind, p.eps);
+            }
+        __syncthreads();
+        for (int pp = 0; pp < 32; ++pp) {
+            const int pi = p0 + wave * 32 + pp;
+            if (pi >= p.P) break;
+            float* orow = dst + ((size_t)grp * p.P + pi) * p.T;
+            for (int t = lane; t < p.T; t += 64) orow[t] = xp[pp * (ROWS + 1) + t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+struct ProtoBwdParams {
+    const float* tok; int64_t stride_b; int t0, T;
+    const float* protos; int B, P, Dp;
+    int act_kind; float eps;
+    const float* dist_full;    // [B][P][T]
+    const float* g_full;       // [B][P][T] upstream grad of act_full, or null
+    const float* g_max;        // [B][P]    upstream grad of act_max, or null
+    const int* argmax;         // [B][P] (null when T == 1)
+    float* dtok;               // written: row(b,i) = dtok + b*dstride_b + (t0+i)*Dp
+    int64_t dstride_b;
+    float* dprotos;            // [P][Dp], accumulated (+=)
+};
+
+__device__ __forceinline__ float dact_dd(float d, int kind, float eps) {
+    if (d <= 0.f) return 0.f;                                       // relu clipped (protopformer.py:216)
+    return kind == 0 ? (1.0f / (d + 1.0f) - 1.0f / (d + eps)) : -1.0f;
+}
+
+// G[b,p,t] = dL/dd
+__device__ __forceinline__ float grad_d(const ProtoBwdParams& p, int b, int pi, int t, int amax, float gmax) {
+    const size_t o = ((size_t)b * p.P + pi) * p.T + t;
+    float g = p.g_full ? p.g_full[o] : 0.f;
+    if (t == amax) g += gmax;
+    if (g == 0.f) return 0.f;
+    return g * dact_dd(p.dist_full[o], p.act_kind, p.eps);
+}
+
+// One workgroup per sample.  Phase 1: all waves stream the sample's (P,T) gradient rows (token-contiguous,
+// coalesced) and mark the non-zero dL/dd entries in an LDS bitmap [T][P bits] (order-independent atomic OR).
+// Phase 2: wave w owns tokens w, w+NW, ... and walks its bitmap row in ascending prototype order, so every
+// token gradient is accumulated in a fixed order (deterministic) from exact fp32 (x - p) differences.
+template <int NJ>
+__global__ __launch_bounds__(1024) void proto_bwd_tokens_kernel(const ProtoBwdParams p) {
+    constexpr int NW = 16;
+    extern __shared__ uint32_t bm[];                  // [T][W]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int W = (p.P + 31) / 32;
+    for (int i = threadIdx.x; i < p.T * W; i += 1024) bm[i] = 0;
+    __syncthreads();
+    for (int pi = wave; pi < p.P; pi += NW) {
+        const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
+        const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
+        for (int tb = 0; tb < p.T; tb += 64) {
+            const int t = tb + lane;
+            if (t < p.T && grad_d(p, b, pi, t, am, gm) != 0.f) atomicOr(&bm[t * W + (pi >> 5)], 1u << (pi & 31));
+        }
+    }
+    __syncthreads();
+    for (int t = wave; t < p.T; t += NW) {
+        const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + t) * p.Dp;
+        float x[NJ], acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; x[j] = d < p.Dp ? xrow[d] : 0.f; acc[j] = 0.f; }
+        for (int w0 = 0; w0 < W; w0 += 64) {
+            const uint32_t mine = (w0 + lane < W) ? bm[t * W + w0 + lane] : 0u;
+            unsigned long long lanes = __ballot(mine != 0u);
+            while (lanes) {
+                const int src = __builtin_ctzll(lanes);
+                lanes &= lanes - 1;
+                uint32_t word = __shfl(mine, src, 64);
+                while (word) {
+                    const int bit = __builtin_ctz(word);
+                    word &= word - 1;
+                    const int pi = (w0 + src) * 32 + bit;
+                    const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
+                    const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
+                    const float g2 = 2.0f * grad_d(p, b, pi, t, am, gm);
+                    const float* prow = p.protos + (size_t)pi * p.Dp;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (x[j] - prow[d]); }
+                }
+            }
+        }
+        float* drow = p.dtok + (size_t)b * p.dstride_b + (size_t)(p.t0 + t) * p.Dp;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) drow[d] = acc[j]; }
+    }
+}
+
+// One workgroup (4 waves) per prototype; wave w owns samples w, w+4, ...; per sample it scans the T tokens.
+template <int NJ>
+__global__ __launch_bounds__(256) void proto_bwd_protos_kernel(const ProtoBwdParams p) {
+    constexpr int NW = 4;
+    __shared__ float red[NW][NJ * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pi = blockIdx.x;
+    const float* prow = p.protos + (size_t)pi * p.Dp;
+    float pv[NJ], acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; pv[j] = d < p.Dp ? prow[d] : 0.f; acc[j] = 0.f; }
+    for (int b = wave; b < p.B; b += NW) {
+        const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
+        const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
+        for (int tb = 0; tb < p.T; tb += 64) {
+            const int t = tb + lane;
+            const float G = t < p.T ? grad_d(p, b, pi, t, am, gm) : 0.f;
+            unsigned long long m = __ballot(G != 0.f);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const float g2 = 2.0f * __shfl(G, src, 64);
+                const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + tb + src) * p.Dp;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (pv[j] - xrow[d]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) red[wave][j * 64 + lane] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NJ * 64; i += 256) {
+        const int d = (i & 63) + 64 * (i >> 6);
+        if (d < p.Dp) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red[w][i];
+            p.dprotos[(size_t)pi * p.Dp + d] += s;           // single writer per (prototype, d)
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// tokens: fp32 rows of Dp values; sample b's token i is at tok + b*stride_b + (t0+i)*Dp, T tokens per sample
+// (T == 1: the global/cls branch, no pooling).  protos [P][Dp].  act_kind 0 = 'log', 1 = 'linear'.
+// Outputs: act_max [B][P], argmax [B][P] (T > 1), optional dist_full / act_full [B][P][T].
+int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
+                  float* act_max, int* argmax, float* dist_full, float* act_full, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && Dp > 0 && Dp % 4 == 0 && T >= 1 && T <= 128, PPF_ERR_SHAPE, "ppf_proto_fwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
+    PPF_CHECK_ARG(tok && protos && act_max && (T == 1 || argmax), PPF_ERR_ARG, "ppf_proto_fwd: null pointer");
+    ProtoFwdParams p;
+    p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
+    p.act_max = act_max; p.argmax = argmax; p.dist_full = dist_full; p.act_full = act_full;
+    const int gx = (P + PB - 1) / PB;
+    if (T == 1) {
+        hipLaunchKernelGGL((proto_fwd_kernel<2, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
+    } else {
+        const int tt = (T + 31) / 32;
+        switch (tt) {
+            case 1: hipLaunchKernelGGL((proto_fwd_kernel<1, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL((proto_fwd_kernel<2, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((proto_fwd_kernel<3, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((proto_fwd_kernel<4, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+        }
+    }
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of ppf_proto_fwd given upstream grads of act_max (g_max) and act_full (g_full), either may be null.
+// dtok rows are overwritten; dprotos [P][Dp] is accumulated (+=).
+int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
+                  const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok, int64_t dstride_b,
+                  float* dprotos, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && Dp > 0 && T >= 1 && Dp <= 512, PPF_ERR_SHAPE, "ppf_proto_bwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
+    PPF_CHECK_ARG(tok && protos && dist_full && (g_full || g_max) && (T == 1 || argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd: null pointer");
+    PPF_CHECK_ARG((size_t)T * ((P + 31) / 32) * 4 <= 64 * 1024, PPF_ERR_SHAPE, "ppf_proto_bwd: T*P bitmap exceeds 64 KiB of LDS (T=%d P=%d)", T, P);
+    ProtoBwdParams p;
+    p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
+    p.dist_full = dist_full; p.g_full = g_full; p.g_max = g_max; p.argmax = (T == 1) ? nullptr : argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
+    const int nj = (Dp + 63) / 64;
+    auto run = [&](auto njc) {
+        constexpr int NJ = decltype(njc)::value;
+        if (dtok) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ>), dim3(B), dim3(1024), (size_t)T * ((P + 31) / 32) * 4, stream, p);
+        if (dprotos) hipLaunchKernelGGL((proto_bwd_protos_kernel<NJ>), dim3(P), dim3(256), 0, stream, p);
+    };
+    if (nj <= 1) run(std::integral_constant<int, 1>());
+    else if (nj <= 2) run(std::integral_constant<int, 2>());
+    else if (nj <= 3) run(std::integral_constant<int, 3>());
+    else if (nj <= 4) run(std::integral_constant<int, 4>());
+    else if (nj <= 6) run(std::integral_constant<int, 6>());
+    else run(std::integral_constant<int, 8>());
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -6,6 +6,12 @@ from . import _lib
 EPI_BF16, EPI_F32, EPI_GELU, EPI_SIGMOID_F32, EPI_RESID, EPI_DGELU, EPI_ATOMIC = range(7)
 
 
+# bench.py's roofline probe: HIP events (on the launch stream) around every launch of one GEMM instantiation
+PROFILE = dict(enabled=False, key=None, events=[], flops=0.0)
+DOMINANT_KEY = (True, True, EPI_ATOMIC)
+DOMINANT_NAME = "gemm_kernel<TA=1,TB=1,EPI_ATOMIC,COLSUM> (weight-gradient bf16 MFMA GEMM, split over the contraction)"
+
+
 def _chk(t, dtype=None):
     assert t.is_cuda and t.is_contiguous(), "kernel operands must be contiguous CUDA tensors"
     if dtype is not None:
@@ -29,9 +35,17 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
     for t in (aux_in, aux_out):
         if t is not None:
             ldaux = t.shape[-1]
+    probe = PROFILE["enabled"] and PROFILE["key"] == (bool(trans_a), bool(trans_b), epi)
+    if probe:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("ppf_gemm_bf16", a, b, out, M, N, K, a.shape[1], b.shape[1], out.shape[-1], int(trans_a), int(trans_b), epi,
               bias, res, res.shape[-1] if res is not None else 0, rowscale, rows_per_group, colscale, aux_in, aux_out, ldaux,
               colsum, float(alpha))
+    if probe:
+        e1.record()
+        PROFILE["events"].append((e0, e1))
+        PROFILE["flops"] += 2.0 * M * N * K
     return out
 
 
@@ -112,3 +126,95 @@ def attn_bwd(qkv, out, dout, rowmax, zinv, B, H, N, D, policy=None, self_keep=Tr
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     _lib.call("ppf_attn_bwd", qkv, out, dout, dqkv, policy, rowmax, zinv, delta, B, H, N, D, int(self_keep))
     return dqkv
+
+
+def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2):
+    """hm: [L,B,N,NP] fp32 head-mean attention. Returns (cls_attn [B,N-lead], idx int32 [B,k] ascending, policy [B,N-lead+1])."""
+    _chk(hm, torch.float32)
+    NP = hm.shape[-1]
+    Nk = N - lead
+    cls_attn = torch.empty((B, Nk), dtype=torch.float32, device=hm.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=hm.device)
+    policy = torch.empty((B, Nk + 1), dtype=torch.float32, device=hm.device)
+    n_init = init_rows.shape[0] if init_rows is not None else 0
+    # discard counts in double precision, exactly like the reference's int(numel * ratio)
+    kdrop, kdrop_init = int(N * N * discard_ratio), int((N + 1) * discard_ratio)
+    _lib.call("ppf_rollout", hm, B * N * NP, L, B, N, NP, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, cls_attn, idx, policy)
+    return cls_attn, idx, policy
+
+
+def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_act=True):
+    """tokens fp32 [B, Ttot, Dp]; uses tokens[:, t0:t0+T]. protos fp32 [P, Dp]."""
+    _chk(tokens, torch.float32), _chk(protos, torch.float32)
+    B, Ttot, Dp = tokens.shape
+    P = protos.shape[0]
+    dev = tokens.device
+    act_max = torch.empty((B, P), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, P), dtype=torch.int32, device=dev) if T > 1 else None
+    dist = torch.empty((B, P, T), dtype=torch.float32, device=dev) if want_dist else None
+    act = torch.empty((B, P, T), dtype=torch.float32, device=dev) if want_act else None
+    _lib.call("ppf_proto_fwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), act_max, argmax, dist, act)
+    return act_max, argmax, dist, act
+
+
+def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4):
+    B, Ttot, Dp = tokens.shape
+    P = protos.shape[0]
+    _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_full, g_max, argmax, dtok,
+              Ttot * Dp, dprotos)
+
+
+def ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh):
+    """act [B,P,T] fp32, idx [B,T] int32, label [B] int64 -> (loss[2] = (cov, mean), gcov, gmean [B,ppc,T])."""
+    B, P, T = act.shape
+    dev = act.device
+    partial = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    gcov = torch.empty((B, ppc, T), dtype=torch.float32, device=dev)
+    gmean = torch.empty((B, ppc, T), dtype=torch.float32, device=dev)
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    _lib.call("ppf_ppc_loss", act, idx, label, B, P, T, ppc, side, float(cov_thresh), float(mean_thresh), partial, gcov, gmean, loss)
+    return loss, gcov, gmean
+
+
+def ppc_loss_bwd(gcov, gmean, up_cov, up_mean, label, P):
+    B, ppc, T = gcov.shape
+    g_full = torch.zeros((B, P, T), dtype=torch.float32, device=gcov.device)
+    _lib.call("ppf_ppc_loss_bwd", gcov, gmean, up_cov, up_mean, label, g_full, B, P, T, ppc)
+    return g_full
+
+
+def cross_entropy(logits, label):
+    B, C = logits.shape
+    per = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    _lib.call("ppf_cross_entropy", logits, label, per, dlogits, loss, B, C)
+    return loss, dlogits
+
+
+def sgemm(a, b, out, M, N, K, sam, sak, sbn, sbk, alpha=1.0, beta=0.0):
+    _lib.call("ppf_sgemm", a, b, out, M, N, K, sam, sak, sbn, sbk, out.shape[-1], float(alpha), float(beta))
+    return out
+
+
+def axpby(x, y, a, b, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("ppf_axpby", x, y, out, float(a), float(b), x.numel())
+    return out
+
+
+def topk_sorted(scores, k):
+    """Ascending indices (int32) of the k largest entries of each row of scores [B, n<=256]."""
+    _chk(scores, torch.float32)
+    B, n = scores.shape
+    idx = torch.empty((B, k), dtype=torch.int32, device=scores.device)
+    _lib.call("ppf_topk_sorted", scores, B, n, k, idx)
+    return idx
+
+
+def sigmoid_bwd(df, f, dbias):
+    rows, cols = f.shape
+    dz = torch.empty((rows, cols), dtype=torch.bfloat16, device=f.device)
+    _lib.call("ppf_sigmoid_bwd", df, f, dz, dbias, rows, cols)
+    return dz

@@ -1,0 +1,336 @@
+"""PPNet on the MI355X kernels: the reference's model API (protopformer.py:12-401, 455-487) as a drop-in.
+
+``construct_PPNet(...)`` / ``PPNet.forward`` / ``get_PPC_loss`` / ``push_forward`` keep the reference's signatures,
+return tuples, attribute names and state-dict keys; underneath, every FLOP runs in the HIP library
+(protopformer_amd/lib/libppf_hip.so, C ABI in include/ppf_hip.h).  Python here wires shapes, autograd and buffers.
+There is no CPU / eager fallback: without the built library or off a GPU, forward() raises.
+"""
+import math
+import os
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbone import DEIT_FNS, TokensFn, droppath_scales
+from .deit import MyVisionTransformer
+from .flat import FlatStore
+
+ARCHS = {
+    "deit_tiny_patch16_224": dict(kind="deit", embed_dim=192, depth=12, num_heads=3),
+    "deit_small_patch16_224": dict(kind="deit", embed_dim=384, depth=12, num_heads=6),
+    "cait_xxs24_224": dict(kind="cait", embed_dim=192, depth=24, num_heads=4, init_scale=1e-5),
+}
+
+
+def _load_pretrained(model, name):
+    """The reference downloads ImageNet weights (deit:296-301); there is no network here, so a local file is required."""
+    root = os.environ.get("PPF_PRETRAINED_DIR", "")
+    path = os.path.join(root, name + ".pth")
+    if not root or not os.path.exists(path):
+        raise FileNotFoundError(f"pretrained=True needs {name}.pth under $PPF_PRETRAINED_DIR (no network access); "
+                                "pass pretrained=False for seeded random init")
+    ck = torch.load(path, map_location="cpu")
+    model.load_state_dict(ck.get("model", ck), strict=False)
+
+
+def build_features(base_architecture, pretrained=False, img_size=224, drop_path=0.1):
+    """tools/deit_features.py:65-90, tools/cait_features.py:4-25: the `features` module of a PPNet."""
+    cfg = dict(ARCHS[base_architecture])
+    kind = cfg.pop("kind")
+    if kind == "deit":
+        m = MyVisionTransformer(img_size=img_size, patch_size=16, drop_path_rate=drop_path, **cfg)
+    else:
+        from .cait import MyCait
+        m = MyCait(img_size=img_size, patch_size=16, drop_path_rate=drop_path, **cfg)
+    if pretrained:
+        _load_pretrained(m, base_architecture)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ autograd nodes
+class ProtoLayerFn(torch.autograd.Function):
+    """get_activations for both branches (protopformer.py:236-247, 311-312)."""
+
+    @staticmethod
+    def forward(ctx, f, protos_local, protos_global, ppnet, want_dist):
+        B, T1, Dp = f.shape
+        k = T1 - 1
+        act_kind = 0 if ppnet.prototype_activation_function == "log" else 1
+        pl = protos_local.reshape(protos_local.shape[0], Dp)
+        pg = protos_global.reshape(protos_global.shape[0], Dp)
+        need_bwd = any(ctx.needs_input_grad)
+        act_l, argmax, dist, act_full = ops.proto_fwd(f, 1, k, pl, act_kind, ppnet.epsilon, want_dist=need_bwd or want_dist, want_act=True)
+        act_g, _, dist_g, _ = ops.proto_fwd(f, 0, 1, pg, act_kind, ppnet.epsilon, want_dist=need_bwd, want_act=False)
+        ctx.set_materialize_grads(False)
+        if need_bwd:
+            ctx.save_for_backward(f, protos_local, protos_global)
+            ctx.aux = (argmax, dist, dist_g, act_kind, ppnet)
+        if dist is None:
+            dist = act_full.new_empty(0)
+        ctx.mark_non_differentiable(dist)
+        return act_l, act_full, act_g, dist
+
+    @staticmethod
+    def backward(ctx, g_l, g_full, g_g, _g_dist):
+        f, _, _ = ctx.saved_tensors
+        argmax, dist, dist_g, act_kind, ppnet = ctx.aux
+        protos_local, protos_global = ppnet.prototype_vectors, ppnet.prototype_vectors_global
+        store = ppnet.flat_store()
+        store.attach_all_grads()
+        B, T1, Dp = f.shape
+        df = torch.zeros_like(f)
+        if g_l is not None or g_full is not None:
+            ops.proto_bwd(f, 1, T1 - 1, protos_local.reshape(-1, Dp), dist, g_full.contiguous() if g_full is not None else None,
+                          g_l.contiguous() if g_l is not None else None, argmax, df, store.grad_view(protos_local).reshape(-1, Dp),
+                          act_kind, ppnet.epsilon)
+        if g_g is not None:
+            ops.proto_bwd(f, 0, 1, protos_global.reshape(-1, Dp), dist_g, None, g_g.contiguous(), None, df,
+                          store.grad_view(protos_global).reshape(-1, Dp), act_kind, ppnet.epsilon)
+        return df, None, None, None, None
+
+
+class LogitsFn(torch.autograd.Function):
+    """logits = coe * act_g W_g^T + (1 - coe) * act_l W_l^T with frozen W (protopformer.py:314-316)."""
+
+    @staticmethod
+    def forward(ctx, act_g, act_l, w_g, w_l, coe):
+        B, C = act_g.shape[0], w_g.shape[0]
+        lg = torch.empty((B, C), dtype=torch.float32, device=act_g.device)
+        ll = torch.empty_like(lg)
+        ops.sgemm(act_g, w_g, lg, B, C, act_g.shape[1], act_g.shape[1], 1, w_g.shape[1], 1)
+        ops.sgemm(act_l, w_l, ll, B, C, act_l.shape[1], act_l.shape[1], 1, w_l.shape[1], 1)
+        logits = ops.axpby(lg, ll, coe, 1.0 - coe)
+        ctx.save_for_backward(w_g, w_l)
+        ctx.coe = coe
+        ctx.mark_non_differentiable(lg, ll)
+        return logits, lg, ll
+
+    @staticmethod
+    def backward(ctx, dlogits, _dlg, _dll):
+        w_g, w_l = ctx.saved_tensors
+        dlogits = dlogits.contiguous()
+        B, C = dlogits.shape
+        dg = torch.empty((B, w_g.shape[1]), dtype=torch.float32, device=dlogits.device)
+        dl = torch.empty((B, w_l.shape[1]), dtype=torch.float32, device=dlogits.device)
+        ops.sgemm(dlogits, w_g, dg, B, w_g.shape[1], C, C, 1, 1, w_g.shape[1], alpha=ctx.coe)
+        ops.sgemm(dlogits, w_l, dl, B, w_l.shape[1], C, C, 1, 1, w_l.shape[1], alpha=1.0 - ctx.coe)
+        return dg, dl, None, None, None
+
+
+class PPCLossFn(torch.autograd.Function):
+    """get_PPC_loss (protopformer.py:259-288): returns (cov_loss, mean_loss)."""
+
+    @staticmethod
+    def forward(ctx, act_full, idx, label, ppc, side, cov_thresh, mean_thresh):
+        act = act_full.reshape(act_full.shape[0], act_full.shape[1], -1).contiguous()
+        loss, gcov, gmean = ops.ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh)
+        ctx.save_for_backward(gcov, gmean, label)
+        ctx.shape = act_full.shape
+        ctx.set_materialize_grads(False)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, up_cov, up_mean):
+        gcov, gmean, label = ctx.saved_tensors
+        uc = up_cov.reshape(1).float().contiguous() if up_cov is not None else None
+        um = up_mean.reshape(1).float().contiguous() if up_mean is not None else None
+        g_full = ops.ppc_loss_bwd(gcov, gmean, uc, um, label, ctx.shape[1])
+        return g_full.reshape(ctx.shape), None, None, None, None, None, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, label):
+        loss, dlogits = ops.cross_entropy(logits.contiguous(), label)
+        ctx.save_for_backward(dlogits)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * up, None          # chain rule with the upstream scalar (autograd bookkeeping)
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() (main.py:390) on the HIP kernel."""
+
+    def forward(self, logits, target):
+        return CrossEntropyFn.apply(logits, target)
+
+
+# ------------------------------------------------------------------------------------------------ PPNet
+class PPNet(nn.Module):
+    def __init__(self, features, img_size, prototype_shape, proto_layer_rf_info, num_classes, reserve_layers=[],
+                 reserve_token_nums=[], use_global=False, use_ppc_loss=False, ppc_cov_thresh=2., ppc_mean_thresh=2,
+                 global_coe=0.3, global_proto_per_class=10, init_weights=True, prototype_activation_function='log',
+                 add_on_layers_type='bottleneck'):
+        super().__init__()
+        if not use_global or len(reserve_layers) != 1:
+            # the reference's use_global=False / empty reserve_layers branches are broken (SURVEY quick facts)
+            raise NotImplementedError("only the working reference configuration is supported: use_global=True with one reserve layer")
+        if add_on_layers_type == 'bottleneck':
+            raise NotImplementedError("add_on_layers_type='bottleneck' is outside the hot path (main.py:49 passes 'regular')")
+        if prototype_activation_function not in ('log', 'linear'):
+            raise NotImplementedError("prototype_activation_function must be 'log' or 'linear'")
+        self.img_size = img_size
+        self.prototype_shape = list(prototype_shape)
+        self.num_prototypes = prototype_shape[0]
+        self.num_classes = num_classes
+        self.reserve_layers = list(reserve_layers)
+        self.reserve_token_nums = list(reserve_token_nums)
+        self.use_global, self.use_ppc_loss = use_global, use_ppc_loss
+        self.ppc_cov_thresh, self.ppc_mean_thresh = ppc_cov_thresh, ppc_mean_thresh
+        self.global_coe = global_coe
+        self.global_proto_per_class = global_proto_per_class
+        self.epsilon = 1e-4
+        self.reserve_layer_nums = list(zip(self.reserve_layers, self.reserve_token_nums))
+        self.num_prototypes_global = num_classes * global_proto_per_class
+        self.prototype_shape_global = [self.num_prototypes_global] + self.prototype_shape[1:]
+        self.prototype_activation_function = prototype_activation_function
+        assert self.num_prototypes % num_classes == 0
+        self.num_prototypes_per_class = self.num_prototypes // num_classes
+        ident = torch.zeros(self.num_prototypes, num_classes)
+        ident[torch.arange(self.num_prototypes), torch.arange(self.num_prototypes) // self.num_prototypes_per_class] = 1
+        ident_g = torch.zeros(self.num_prototypes_global, num_classes)
+        ident_g[torch.arange(self.num_prototypes_global), torch.arange(self.num_prototypes_global) // global_proto_per_class] = 1
+        self.prototype_class_identity, self.prototype_class_identity_global = ident, ident_g
+        self.proto_layer_rf_info = proto_layer_rf_info
+        self.features = features
+        features._ppf_root = weakref.ref(self)
+        k = self.reserve_token_nums[0]
+        assert int(round(math.sqrt(k))) ** 2 == k, "reserve token number must be a perfect square (protopformer.py:165)"
+        in_ch = features.embed_dim
+        self.num_patches = features.patch_embed.num_patches
+        self.add_on_layers = nn.Sequential(nn.Conv2d(in_ch, self.prototype_shape[1], kernel_size=1), nn.Sigmoid())
+        self.prototype_vectors = nn.Parameter(torch.rand(self.prototype_shape), requires_grad=True)
+        self.prototype_vectors_global = nn.Parameter(torch.rand(self.prototype_shape_global), requires_grad=True)
+        self.ones = nn.Parameter(torch.ones(self.prototype_shape), requires_grad=False)
+        self.last_layer = nn.Linear(self.num_prototypes, num_classes, bias=False)
+        self.last_layer_global = nn.Linear(self.num_prototypes_global, num_classes, bias=False)
+        self.last_layer.weight.requires_grad = False
+        self.last_layer_global.weight.requires_grad = False
+        self.all_attn_mask = None
+        self.teacher_model = None
+        self.scale = self.prototype_shape[1] ** -0.5
+        self._flat = None
+        self._ppc_cache = None
+        from .backbone import DEIT_FNS
+        if isinstance(features, MyVisionTransformer):
+            self._arch_fns = DEIT_FNS
+        else:
+            from .cait import CAIT_FNS
+            self._arch_fns = CAIT_FNS
+        if init_weights:
+            self._initialize_weights()
+
+    # ---- flat parameter store (lazy: built at first use on the device the module lives on)
+    def flat_store(self):
+        if self._flat is None or not self._flat.still_flat():
+            dev = self.prototype_vectors.device
+            if dev.type != "cuda":
+                raise RuntimeError("protopformer_amd runs on an MI355X only: move the model to cuda (no CPU fallback path)")
+            groups = [("features", list(self.features.named_parameters())), ("add_on_layers", list(self.add_on_layers.named_parameters())),
+                      ("prototype_vectors", [("prototype_vectors", self.prototype_vectors)]),
+                      ("prototype_vectors_global", [("prototype_vectors_global", self.prototype_vectors_global)])]
+            self._flat = FlatStore(self, groups)
+        return self._flat
+
+    def _hook_params(self):
+        return [p for p in list(self.features.parameters()) + list(self.add_on_layers.parameters()) if p.requires_grad]
+
+    def _apply(self, fn, *a, **k):                    # .to()/.cuda()/.float(): the flat views are re-created lazily
+        self._flat = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        if self._flat is not None:
+            self._flat.invalidate()
+        return out
+
+    # ---- reference API
+    def distance_2_similarity(self, distances):
+        """protopformer.py:228-234 on an arbitrary tensor (elementwise helper kept for API parity; eval tools call it)."""
+        if self.prototype_activation_function == 'log':
+            return torch.log((distances + 1) / (distances + self.epsilon))
+        return -distances
+
+    def _tokens(self, x):
+        B = x.shape[0]
+        rates = self.features.droppath_rates()
+        dp = droppath_scales(rates, B, x.device, self.training)
+        return TokensFn.apply(x, self, dp, *self._hook_params())
+
+    def _branches(self, x, want_dist):
+        f, cls_attn, idx = self._tokens(x)
+        act_l, act_full, act_g, dist = ProtoLayerFn.apply(f, self.prototype_vectors, self.prototype_vectors_global, self, want_dist)
+        logits, lg, ll = LogitsFn.apply(act_g, act_l, self.last_layer_global.weight, self.last_layer.weight, float(self.global_coe))
+        return f, cls_attn, idx, act_full, dist, logits, lg, ll
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("protopformer_amd.PPNet.forward needs a CUDA/HIP tensor (no CPU fallback path)")
+        B = x.shape[0]
+        k = self.reserve_token_nums[0]
+        s = int(round(math.sqrt(k)))
+        if not self.training:
+            with torch.no_grad():
+                f, cls_attn, idx, act_full, dist, logits, lg, ll = self._branches(x, want_dist=True)
+            return logits, (cls_attn, dist.reshape(B, self.num_prototypes, s, s), lg, ll)
+        f, cls_attn, idx, act_full, dist, logits, lg, ll = self._branches(x, want_dist=False)
+        self._ppc_cache = (cls_attn, idx)
+        total_proto_act = act_full.reshape(B, self.num_prototypes, s, s)
+        attn_loss = torch.zeros(1, device=logits.device)
+        return logits, (None, attn_loss, total_proto_act, cls_attn, self.num_patches)
+
+    def push_forward(self, x):
+        with torch.no_grad():
+            f, cls_attn, idx, act_full, dist, logits, lg, ll = self._branches(x, want_dist=False)
+        k = self.reserve_token_nums[0]
+        s = int(round(math.sqrt(k)))
+        return cls_attn, act_full.reshape(x.shape[0], self.num_prototypes, s, s)
+
+    def get_PPC_loss(self, total_proto_act, cls_attn_rollout, original_fea_len, label):
+        k = total_proto_act.shape[-1] * total_proto_act.shape[-2]
+        cache = self._ppc_cache
+        if cache is not None and cache[0] is cls_attn_rollout:
+            idx = cache[1]                                  # same top-k + sort result the backbone already produced
+        else:
+            idx = ops.topk_sorted(cls_attn_rollout.contiguous().float(), k)
+        side = int(original_fea_len ** 0.5)
+        return PPCLossFn.apply(total_proto_act, idx, label.contiguous(), self.num_prototypes_per_class, side,
+                               float(self.ppc_cov_thresh), float(self.ppc_mean_thresh))
+
+    def set_last_layer_incorrect_connection(self, incorrect_strength):
+        pos = torch.t(self.prototype_class_identity)
+        self.last_layer.weight.data.copy_(pos + incorrect_strength * (1 - pos))
+        pos_g = torch.t(self.prototype_class_identity_global)
+        self.last_layer_global.weight.data.copy_(pos_g + incorrect_strength * (1 - pos_g))
+
+    def _initialize_weights(self):
+        for m in self.add_on_layers.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        self.set_last_layer_incorrect_connection(incorrect_strength=-0.5)
+
+    def __repr__(self):
+        return (f"PPNet(\n\tfeatures: {self.features.__class__.__name__},\n\timg_size: {self.img_size},\n\tprototype_shape: "
+                f"{self.prototype_shape},\n\tproto_layer_rf_info: {self.proto_layer_rf_info},\n\tnum_classes: {self.num_classes},\n"
+                f"\tepsilon: {self.epsilon}\n)")
+
+
+def construct_PPNet(base_architecture, pretrained=True, img_size=224, prototype_shape=(2000, 512, 1, 1), num_classes=200,
+                    reserve_layers=[], reserve_token_nums=[], use_global=False, use_ppc_loss=False, ppc_cov_thresh=1.,
+                    ppc_mean_thresh=2., global_coe=0.5, global_proto_per_class=10, prototype_activation_function='log',
+                    add_on_layers_type='bottleneck'):
+    """Same signature and defaults as the reference (protopformer.py:455-487)."""
+    features = build_features(base_architecture, pretrained=pretrained, img_size=img_size)
+    return PPNet(features=features, img_size=img_size, prototype_shape=list(prototype_shape), proto_layer_rf_info=[14, 16, 16, 8.0],
+                 num_classes=num_classes, reserve_layers=reserve_layers, reserve_token_nums=reserve_token_nums, use_global=use_global,
+                 use_ppc_loss=use_ppc_loss, ppc_cov_thresh=ppc_cov_thresh, ppc_mean_thresh=ppc_mean_thresh, global_coe=global_coe,
+                 global_proto_per_class=global_proto_per_class, init_weights=True,
+                 prototype_activation_function=prototype_activation_function, add_on_layers_type=add_on_layers_type)

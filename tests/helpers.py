@@ -24,8 +24,8 @@ def micro(name):
 
 
 def rel_err(a, b):
-    a = torch.as_tensor(a, dtype=torch.float64)
-    b = torch.as_tensor(b, dtype=torch.float64)
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 

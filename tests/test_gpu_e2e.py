@@ -1,0 +1,156 @@
+"""End-to-end GPU parity of the drop-in PPNet (HIP kernels) against the reference-generated micro fixtures and the oracle.
+
+The backbone GEMMs run with bf16 operands / fp32 accumulation (BASELINE.json: "1xMI355X bf16"), so end-to-end numbers
+carry bf16 rounding (~4e-3 per operand); tolerances below are stated per quantity.  Op-level kernels are held to 1e-3
+against the oracle on identical inputs in the other test_gpu_* files; reserved-token indices are bit-exact given
+identical fp32 cls_token_attn (test_gpu_head.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, micro, rel_err
+from oracle import ppf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cfg, sd):
+    from protopformer_amd.deit import MyVisionTransformer
+    from protopformer_amd.protopformer import PPNet
+    assert cfg["arch"] == "deit"
+    feats = MyVisionTransformer(img_size=cfg["img"], patch_size=16, embed_dim=cfg["dim"], depth=cfg["depth"], num_heads=cfg["heads"],
+                                drop_path_rate=0.0)
+    m = PPNet(features=feats, img_size=cfg["img"], prototype_shape=[cfg["num_prototypes"], cfg["proto_dim"], 1, 1], proto_layer_rf_info=None,
+              num_classes=cfg["num_classes"], reserve_layers=[cfg["reserve_layer"]], reserve_token_nums=[cfg["reserve_k"]], use_global=True,
+              use_ppc_loss=True, ppc_cov_thresh=1., ppc_mean_thresh=2., global_coe=cfg["global_coe"],
+              global_proto_per_class=cfg["global_per_class"], add_on_layers_type="regular")
+    missing = m.load_state_dict(sd, strict=True)          # reference state-dict keys must match exactly
+    return m.cuda()
+
+
+def test_micro_deit_eval_train_against_reference_fixture():
+    from protopformer_amd.protopformer import CrossEntropyLoss
+    sd, cfg, z = micro("micro_deit.npz")
+    m = _build(cfg, sd)
+    img, label = torch.from_numpy(z["img"]).cuda(), torch.from_numpy(z["label"]).cuda()
+    m.eval()
+    logits, (cls_attn, dist, lg, ll) = m(img)
+    assert dist.shape == z["eval/distances"].shape
+    assert_close(cls_attn, z["eval/cls_token_attn"], rtol=3e-2, atol=1e-4, what="cls_token_attn (bf16 backbone)")
+    ref_idx = torch.from_numpy(z["eval/cls_token_attn"]).topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
+    my_idx = cls_attn.cpu().topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
+    assert torch.equal(my_idx, ref_idx), "reserved tokens differ from the reference on the micro fixture"
+    # bf16 operand rounding through 3 blocks feeding the steep log-similarity of a tiny head (P=20, Dp=32, 9 tokens: nothing
+    # averages out): measured 3.3e-2 on the logits here, 1.5e-3 at real shapes (next test)
+    TOL = 6e-2
+    assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+    assert rel_err(lg, z["eval/logits_global"]) < TOL and rel_err(ll, z["eval/logits_local"]) < TOL
+    cls2, acts = m.push_forward(img)
+    assert rel_err(acts, z["eval/push_proto_acts"]) < 0.15
+
+    m.train()
+    crit = CrossEntropyLoss()
+    logits, aux = m(img)
+    assert aux[0] is None and aux[4] == 16 and aux[2].shape == z["train/total_proto_act"].shape
+    ce = crit(logits, label)
+    cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label)
+    loss = ce + 0.1 * cov + 0.5 * mean
+    for name, val in (("ce", ce), ("ppc_cov", cov), ("ppc_mean", mean), ("loss", loss)):
+        assert rel_err(val, z[f"train/{name}"]) < TOL, (name, float(val), float(z[f"train/{name}"]))
+    loss.backward()
+    # Gradients vs the reference fixture.  Two effects bound the agreement (measured with scripts/diag_e2e.py):
+    #  * bf16 operands in every backward GEMM: per-tensor cosine >= 0.997 on a max-pool-free loss (next test);
+    #  * max-pool arg-max routing is discontinuous: a bf16-level change of a near-tied activation moves a prototype's
+    #    whole gradient to another token, which shows up in every upstream tensor (cosine ~0.97-0.99).
+    cos = {}
+    for name, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        g = p.grad.detach().float().cpu().reshape(-1)
+        if f"grad/{name}" in z.files:
+            ref = torch.from_numpy(z[f"grad/{name}"]).reshape(-1)
+        else:
+            idx = torch.from_numpy(z[f"grad_idx/{name}"]); ref = torch.from_numpy(z[f"grad_val/{name}"]); g = g[idx]
+        if float(ref.abs().max()) < 1e-7:
+            continue
+        cos[name] = float(torch.dot(g, ref) / (g.norm() * ref.norm()))
+    bad = {k: v for k, v in cos.items() if v < 0.93}
+    assert not bad, f"gradient direction mismatch vs reference: {bad}"
+
+
+def _grad_agreement(m, params):
+    rows = {}
+    for name, p in m.named_parameters():
+        if not p.requires_grad or params[name].grad is None:
+            continue
+        gm, gr = p.grad.float().cpu().reshape(-1), params[name].grad.reshape(-1)
+        if float(gr.abs().max()) < 1e-12:
+            continue
+        rows[name] = (float((gm - gr).abs().max() / gr.abs().max()), float(torch.dot(gm, gr) / (gm.norm() * gr.norm())))
+    return rows
+
+
+def test_real_shape_train_step_vs_oracle():
+    """deit_tiny architecture, B=4: forward losses and a few gradients vs the fp32 CPU oracle with bf16-rounded weights."""
+    from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
+    torch.manual_seed(0)
+    cfg = O.make_cfg("deit_tiny_patch16_224", 200, 64, 20, 11, 81, global_per_class=5)
+    sd = O.init_state_dict(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    for k_ in sd:                                               # non-trivial LN / bias values
+        if k_.endswith(".bias") and "add_on" not in k_:
+            sd[k_] = 0.05 * torch.randn(sd[k_].shape, generator=g)
+        if "qkv.weight" in k_:
+            sd[k_] = sd[k_] * 6.0                               # peaky attention => a well-separated top-k
+    m = construct_PPNet("deit_tiny_patch16_224", pretrained=False, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[11],
+                        reserve_token_nums=[81], use_global=True, use_ppc_loss=True, global_proto_per_class=5, add_on_layers_type="regular")
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    for blk in m.features.blocks:
+        blk.drop_path_rate = 0.0
+    img = torch.randn(4, 3, 224, 224, generator=g); label = torch.tensor([3, 0, 19, 3])
+    m.train()
+    logits, aux = m(img.cuda())
+    ce = CrossEntropyLoss()(logits, label.cuda())
+    cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label.cuda())
+    (ce + 0.1 * cov + 0.5 * mean).backward()
+    params = {k: v.clone().requires_grad_(k not in O.FROZEN_KEYS) for k, v in sd.items()}
+    my_idx = m._ppc_cache[1].cpu().long()
+    with torch.no_grad():
+        free = O.ppnet_forward(sd, img, cfg, train=True)
+    assert_close(aux[3], free["cls_token_attn"], rtol=5e-2, atol=2e-4, what="cls rollout")
+    # bf16 perturbs cls_token_attn by up to ~5e-2 relative: the reservation must agree with the fp32 oracle on every token
+    # whose score is outside that band around the k-th value (exactness is only attainable at the kernel boundary)
+    ref_attn = free["cls_token_attn"]
+    kth = ref_attn.topk(81, dim=-1)[0][:, -1:]
+    sel = torch.zeros_like(ref_attn, dtype=torch.bool).scatter_(1, my_idx, True)
+    assert bool(sel[ref_attn > kth * 1.06].all()) and not bool(sel[ref_attn < kth * 0.94].any())
+    n_diff = int((sel != torch.zeros_like(sel).scatter_(1, free["reserve_idx"], True)).sum()) // 2
+    print(f"reserved tokens differing from the fp32 oracle: {n_diff} of {my_idx.numel()}")
+    # downstream parity with the oracle following the SAME reservation
+    out = O.ppnet_forward(params, img, cfg, train=True, force_idx=my_idx)
+    loss_ref, parts = O.train_loss(out, label, cfg, with_ppc=True)
+    loss_ref.backward()
+    assert rel_err(logits, out["logits"]) < 3e-2
+    assert rel_err(ce, parts["ce"]) < 3e-2 and rel_err(cov, parts["ppc_cov"]) < 5e-2 and rel_err(mean, parts["ppc_mean"]) < 5e-2
+    rows = _grad_agreement(m, params)
+    assert min(c for _, c in rows.values()) > 0.93, {k: v for k, v in rows.items() if v[1] <= 0.93}     # arg-max routing flips, see above
+
+    # backbone backward in isolation: L = sum(w * f) on the add-on tokens (no max-pool routing) -> every parameter gradient
+    # must agree with the oracle's autograd up to bf16 operand rounding accumulated over 12 layers
+    m.flat_store().zero_grad()
+    f, _, idx = m._tokens(img.cuda())
+    w = torch.randn(f.shape, generator=g)
+    (f * w.cuda()).sum().backward()
+    params = {k: v.clone().requires_grad_(k not in O.FROZEN_KEYS) for k, v in sd.items()}
+    out = O.ppnet_forward(params, img, cfg, train=True, force_idx=idx.cpu().long())
+    fo = torch.cat([out["cls_tokens"], out["tokens"]], dim=1)
+    assert rel_err(f, fo) < 8e-2
+    (fo * w).sum().backward()
+    rows = _grad_agreement(m, params)
+    assert len(rows) > 140
+    rels = sorted(r for r, _ in rows.values())
+    worst_cos = min(c for _, c in rows.values())
+    # measured: cosine >= 0.997 for every tensor, rel-to-max error median 3e-2, worst 0.2 (bf16 drift over 12 peaky layers)
+    assert worst_cos > 0.99 and rels[len(rels) // 2] < 6e-2 and rels[-1] < 0.3, (rels[len(rels) // 2], rels[-1], worst_cos)

@@ -1,0 +1,159 @@
+"""GPU parity of rollout / prototype layer / PPC / CE / frozen-head kernels vs the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from helpers import assert_close, load_npz
+from oracle import ppf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad_hm(fused):
+    """[L,B,N,N] -> kernel layout [L,B,N,NP] with NP = N rounded up to 4."""
+    L, B, N, _ = fused.shape
+    NP = (N + 3) // 4 * 4
+    out = torch.zeros(L, B, N, NP)
+    out[..., :N] = fused
+    return out.cuda()
+
+
+def _check_topk(idx, ref, k):
+    """Tie-robust top-k check (torch.topk's tie order is implementation-defined): every index strictly
+    above the k-th value must be selected, none strictly below it, indices ascending and unique."""
+    kth = ref.topk(k, dim=-1)[0][:, -1:]
+    sel = torch.zeros_like(ref, dtype=torch.bool)
+    sel.scatter_(1, idx, True)
+    assert int(sel.sum()) == idx.numel(), "duplicate indices"
+    assert bool((idx[:, 1:] > idx[:, :-1]).all()), "indices must be ascending"
+    assert bool(sel[ref > kth].all()) and not bool(sel[ref < kth].any())
+
+
+def test_rollout_deit_golden():
+    from protopformer_amd import ops
+    z = load_npz("ops_real.npz")
+    probs = gi.rollout_inputs()
+    fused = torch.stack([p.mean(1) for p in probs])                      # head fusion is the attention kernel's job
+    cls_attn, idx, policy = ops.rollout(_pad_hm(fused), 11, 2, 197, 81, lead=1)
+    assert_close(cls_attn, z["rollout/cls_token_attn"], rtol=1e-3, atol=1e-8, what="cls_token_attn vs reference")
+    assert np.array_equal(idx.cpu().numpy(), z["rollout/idx"]), "reserved-token indices must be bit-exact"
+    pol = torch.zeros(2, 197); pol[:, 0] = 1
+    pol.scatter_(1, torch.from_numpy(z["rollout/idx"]).long() + 1, 1.0)
+    assert torch.equal(policy.cpu(), pol)
+
+
+@pytest.mark.parametrize("B,N,L,k", [(3, 17, 2, 9), (2, 65, 3, 16), (5, 197, 1, 81)])
+def test_rollout_deit_vs_oracle(B, N, L, k):
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(N)
+    probs = [torch.softmax(2.0 * torch.randn(B, 2, N, N, generator=g), dim=-1) for _ in range(L)]
+    R = O.deit_rollout(probs)
+    ref = R[:, 0, 1:]
+    fused = torch.stack([p.mean(1) for p in probs])
+    cls_attn, idx, _ = ops.rollout(_pad_hm(fused), L, B, N, k, lead=1)
+    assert_close(cls_attn, ref, rtol=1e-3, atol=1e-8, what="cls_token_attn")
+    _check_topk(idx.cpu().long(), ref, k)
+
+
+def test_rollout_cait_golden():
+    from protopformer_amd import ops
+    z = load_npz("ops_real.npz")
+    c = gi.cait_inputs()
+    fused = torch.stack([p.mean(1) for p in c["sa"]])
+    init = torch.stack([p.mean(1)[:, 0] for p in c["cas"]])                 # [n_init, B, N+1]
+    cls_attn, idx, policy = ops.rollout(_pad_hm(fused), 4, c["B"], c["N"], 121, lead=0, init_rows=init.cuda().contiguous())
+    ref = torch.from_numpy(z["cait/rollout_cls"])
+    assert_close(cls_attn, ref, rtol=1e-3, atol=1e-8, what="cait cls rollout vs reference")
+    assert torch.equal(idx.cpu().long(), O.topk_sorted(ref, 121))
+
+
+def test_proto_fwd_golden_and_kat():
+    from protopformer_amd import ops
+    z = load_npz("ops_real.npz")
+    tok, protos = gi.proto_inputs()
+    tokens = tok.flatten(2).transpose(1, 2).contiguous()                    # (B,81,Dp)
+    act_max, argmax, dist, act = ops.proto_fwd(tokens.cuda(), 0, 81, protos.reshape(2000, -1).cuda())
+    idx = torch.from_numpy(z["proto/dist_idx"])
+    # d compared with abs 1e-6*(x2+p2) (~1e-4) or rel 1e-3
+    assert_close(dist.reshape(-1).cpu()[idx], z["proto/dist_val"], rtol=1e-3, atol=2e-4, what="distances vs reference")
+    assert float(dist[1, 7, 0]) == 0.0                                       # exactly representable token == prototype
+    assert abs(float(act[1, 7, 0]) - 9.21034) < 1e-4
+    assert float(dist[0, 5].reshape(9, 9)[2, 3]) < 1e-4
+    ref_max = torch.from_numpy(z["proto/act_max"])
+    far = ref_max < 2.9                                                      # d >= 0.05: outside the steep region
+    assert_close(act_max.cpu()[far], ref_max[far], rtol=1e-3, what="max-pooled activation (d>=0.05)")
+    # internal consistency: max/argmax agree with the materialised map
+    mx, am = act.max(dim=-1)
+    assert torch.equal(mx, act_max)
+    assert torch.equal(torch.gather(act, 2, argmax.long()[..., None])[..., 0], act_max)
+
+
+@pytest.mark.parametrize("B,T,Dp,P", [(3, 9, 32, 20), (2, 121, 192, 200), (130, 1, 64, 50), (4, 81, 384, 300)])
+def test_proto_fwd_bwd_vs_oracle(B, T, Dp, P):
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(T)
+    tokens = torch.rand(B, T + 1, Dp, generator=g)
+    protos = torch.rand(P, Dp, generator=g)
+    t0 = 1 if T > 1 else 0
+    xt = tokens.clone().requires_grad_(True); pr = protos.clone().requires_grad_(True)
+    mx, d_ref, a_ref = O.proto_activations(xt[:, t0:t0 + T], pr)
+    gmax = torch.randn(B, P, generator=g)
+    gfull = torch.zeros(B, P, T)
+    gfull[:, : max(1, P // 10)] = torch.randn(B, max(1, P // 10), T, generator=g)     # PPC-like sparse rows
+    ((mx * gmax).sum() + (a_ref * gfull).sum()).backward()
+    act_max, argmax, dist, act = ops.proto_fwd(tokens.cuda(), t0, T, protos.cuda())
+    assert_close(dist, d_ref.detach(), rtol=1e-3, atol=1e-6 * Dp, what="dist")
+    ok = d_ref.detach() > 0.05
+    assert_close(act.cpu()[ok], a_ref.detach()[ok], rtol=1e-3, what="act")
+    dtok = torch.zeros(B, T + 1, Dp, device="cuda"); dpro = torch.zeros(P, Dp, device="cuda")
+    ops.proto_bwd(tokens.cuda(), t0, T, protos.cuda(), dist, gfull.cuda(), gmax.cuda(), argmax, dtok, dpro)
+    assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens")
+    assert_close(dpro, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes")
+
+
+def test_ppc_loss_golden_and_grad():
+    from protopformer_amd import ops
+    z = load_npz("ops_real.npz")
+    tpa, roll, lab = gi.ppc_inputs()
+    idx = O.topk_sorted(roll, 81).int()
+    act = tpa.flatten(2).contiguous()
+    loss, gcov, gmean = ops.ppc_loss(act.cuda(), idx.cuda(), lab.cuda(), 10, 14, 1.0, 2.0)
+    assert_close(loss[0], z["ppc/cov"], rtol=1e-4, atol=1e-6, what="ppc cov vs reference")
+    assert_close(loss[1], z["ppc/mean"], rtol=1e-4, atol=1e-6, what="ppc mean vs reference")
+    a = act.clone().requires_grad_(True)
+    cov, mean = O.ppc_loss(a.reshape(4, 200, 9, 9), roll, 196, lab, 10, 1.0, 2.0)
+    (0.3 * cov + 0.7 * mean).backward()
+    up = torch.tensor([0.3, 0.7], device="cuda")
+    g_full = ops.ppc_loss_bwd(gcov, gmean, up[0:1], up[1:2], lab.cuda(), 200)
+    assert_close(g_full, a.grad, rtol=1e-3, atol=1e-7, what="ppc grad")
+
+
+def test_ppc_known_answer():
+    from protopformer_amd import ops
+    act = torch.ones(2, 200, 196, device="cuda")
+    idx = torch.arange(196, dtype=torch.int32, device="cuda").repeat(2, 1).contiguous()
+    loss, _, _ = ops.ppc_loss(act, idx, torch.tensor([0, 5], device="cuda"), 10, 14, 1.0, 2.0)
+    assert abs(float(loss[0]) - (16.25 * 196 / 195 - 1)) < 1e-4 and abs(float(loss[1]) - 1.8) < 1e-5
+
+
+def test_cross_entropy_and_frozen_head():
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, C, P = 37, 200, 2000
+    logits = torch.randn(B, C, generator=g) * 3
+    lab = torch.randint(0, C, (B,), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, lab); ref.backward()
+    loss, dl = ops.cross_entropy(logits.cuda(), lab.cuda())
+    assert_close(loss[0], ref.detach(), rtol=1e-5, atol=1e-6, what="ce")
+    assert_close(dl, lr.grad, rtol=1e-4, atol=1e-7, what="dlogits")
+    act = torch.rand(B, P, generator=g) * 5
+    sd = O.init_state_dict(dict(O.make_cfg("deit_tiny_patch16_224", P, 192, C, 11, 81), depth=1), seed=0)
+    w = sd["last_layer.weight"]
+    out = torch.empty(B, C, device="cuda")
+    ops.sgemm(act.cuda(), w.cuda(), out, B, C, P, P, 1, P, 1, alpha=0.5)
+    assert_close(out, 0.5 * act @ w.t(), rtol=1e-4, atol=1e-3, what="frozen head logits")
+    dact = torch.empty(B, P, device="cuda")
+    ops.sgemm(dl, w.cuda(), dact, B, P, C, C, 1, 1, P, alpha=0.5)            # dA = dlogits @ W
+    assert_close(dact, 0.5 * lr.grad @ w, rtol=1e-4, atol=1e-6, what="frozen head dgrad")
