@@ -16,6 +16,7 @@
 #ifndef PPF_HIP_H
 #define PPF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,7 +47,9 @@ int ppf_device_info(int* cu_count, int* clock_mhz, char* name, int name_len);
 int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int epi, const float* bias, const float* res, int ldres, const float* rowscale,
                   int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,
-                  float alpha, ppf_stream_t stream);
+                  float alpha, void* workspace, size_t workspace_bytes, ppf_stream_t stream);
+/* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic two-pass reduction instead of atomics) */
+size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
 /* ---- LayerNorm (deit:67,72,238 norm1/norm2/norm, eps 1e-6) ----------------------------------------------------
  * fwd: y bf16 [rows][D] = LN(x fp32 [row_map ? row_map[r] : r][D]); saves mean / rstd per output row.
@@ -87,7 +90,8 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
                   float eps, float* act_max, int* argmax, float* dist_full, float* act_full, ppf_stream_t stream);
 int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
                   float eps, const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok,
-                  int64_t dstride_b, float* dprotos, ppf_stream_t stream);
+                  int64_t dstride_b, float* dprotos, void* zeroed_workspace, size_t workspace_bytes, ppf_stream_t stream);
+/* (workspace: B*T*ceil(P/32)*4 bytes, zero-filled by the caller: bitmap of the non-zero dL/dd entries) */
 
 /* ---- losses and the frozen class-connection head ------------------------------------------------------------------
  * PPC loss (protopformer.py:249-288): loss[0] = cov term, loss[1] = mean term; gcov/gmean [B][ppc][T] analytic grads. */

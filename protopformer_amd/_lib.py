@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
 
 # signature spec per entry point: p = device/host pointer, i = int32, l = int64, f = float, s = hipStream_t
 SIGS = {
-    "ppf_gemm_bf16": "pppiiiiiiiiippipipppipfs",
+    "ppf_gemm_bf16": "pppiiiiiiiiippipipppipf" "pz" "s",
     "ppf_device_info": "pppi",
     "ppf_layernorm_fwd": "ppppppp" "iif" "s",
     "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "s",
@@ -25,7 +25,7 @@ SIGS = {
     "ppf_attn_bwd": "pppppppp" "iiiii" "s",
     "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "ppp" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
-    "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "s",
+    "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",
     "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
     "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",
     "ppf_cross_entropy": "ppppp" "ii" "s",
@@ -35,7 +35,7 @@ SIGS = {
     "ppf_sigmoid_bwd": "ppppiis",
 }
 
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "s": ctypes.c_void_p}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
 
 
@@ -48,6 +48,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ppf_last_error.restype = ctypes.c_char_p
         _lib.ppf_abi_version.restype = ctypes.c_int
+        _lib.ppf_gemm_workspace_bytes.restype = ctypes.c_size_t
+        _lib.ppf_gemm_workspace_bytes.argtypes = [ctypes.c_int] * 3
         for name, spec in SIGS.items():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_int

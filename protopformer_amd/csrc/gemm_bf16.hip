@@ -24,7 +24,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile (either mode)
 
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_SIGMOID_F32 = 3, EPI_RESID = 4, EPI_DGELU = 5, EPI_ATOMIC = 6 };
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_SIGMOID_F32 = 3, EPI_RESID = 4, EPI_DGELU = 5, EPI_ATOMIC = 6, EPI_PARTIAL = 7 };
 
 struct GemmParams {
     const bf16_t* A; const bf16_t* B; void* C;
@@ -39,6 +39,7 @@ struct GemmParams {
     bf16_t* aux_out;         // EPI_GELU: pre-activation out; EPI_RESID: raw branch output (optional)
     int ldaux;
     float* colsum;           // EPI_ATOMIC + TA: sum over kc of A(m,kc) accumulated atomically into colsum[m]
+    float* ws;               // EPI_PARTIAL: split-K workspace [nsplit][M*N (+M)] fp32 partial tiles (+ partial column sums)
     float alpha;
 };
 
@@ -110,6 +111,11 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
         float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) unsafeAtomicAdd(c + i, v[i]);
+        return;
+    }
+    if constexpr (EPI == EPI_PARTIAL) {
+        const size_t slice = (size_t)p.M * p.N + (p.colsum ? p.M : 0);
+        *reinterpret_cast<float4*>(p.ws + blockIdx.z * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
         return;
     }
     if (p.bias) {
@@ -252,7 +258,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
             }
         }
         if constexpr (COLSUM) {
-            if (do_colsum && h == 0) unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
+            if (do_colsum && h == 0) {
+                if constexpr (EPI == EPI_PARTIAL) p.ws[blockIdx.z * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
+                else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
+            }
         }
     }
 }
@@ -272,27 +281,62 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream) {
     return 0;
 }
 
+// out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the M partial column sums
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, float* __restrict__ colsum,
+                                                            int M, int N, int ldc, int nsplit) {
+    const size_t mn = (size_t)M * N, slice = mn + (colsum ? M : 0);
+    const size_t total4 = mn / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4 + (colsum ? M : 0); i += (size_t)gridDim.x * 256) {
+        if (i < total4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < nsplit; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(ws + z * slice + i * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            const size_t e = i * 4, m = e / N, n = e - m * N;
+            float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+            float4 c = *dst;
+            *dst = make_float4(c.x + acc.x, c.y + acc.y, c.z + acc.z, c.w + acc.w);
+        } else {
+            const size_t m = i - total4;
+            float acc = 0.f;
+            for (int z = 0; z < nsplit; ++z) acc += ws[z * slice + mn + m];
+            colsum[m] += acc;
+        }
+    }
+}
+
 int pick_splitk(int M, int N, int K) {
     // wgrad-style problems (small output, very long contraction): spread over ~2 workgroups per CU
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int s = (512 + tiles - 1) / tiles;
     const int maxs = (K + 4 * BK - 1) / (4 * BK);      // at least 4 K-tiles per slice
     if (s > maxs) s = maxs;
-    return s < 1 ? 1 : s;
+    if (s < 1) s = 1;
+    // slices are BK-aligned chunks: drop the ones that would be empty (a partial-tile slice must always be written)
+    const int kchunk = (((K + s - 1) / s) + BK - 1) / BK * BK;
+    return (K + kchunk - 1) / kchunk;
 }
 
 }  // namespace
 
 extern "C" {
 
+// Bytes of split-K workspace ppf_gemm_bf16 needs for an accumulating (epi = 6) problem of this shape.
+size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
+    return (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
+}
+
 // Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
 // epi: 0 bf16 out, 1 f32 out, 2 bias+GELU (C = gelu bf16, aux_out = pre-activation bf16), 3 sigmoid f32 out,
 //      4 residual (C f32 = res + rowscale*colscale*(acc+bias), optional aux_out raw bf16), 5 dGELU (C bf16 = acc*gelu'(aux_in)),
-//      6 atomic f32 accumulate into C (split over the contraction; optional colsum of A when trans_a).
+//      6 f32 accumulate into C (C += ...; split over the contraction; optional colsum[m] += sum_kc A(m,kc) when trans_a).
+//        With a workspace of ppf_gemm_workspace_bytes(M,N,K) the slices write partial tiles that a second kernel reduces in a
+//        fixed order (deterministic, no atomics); without one the slices fall back to fp32 atomics on C.
 int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int epi, const float* bias, const float* res, int ldres, const float* rowscale,
                   int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,
-                  float alpha, hipStream_t stream) {
+                  float alpha, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     PPF_CHECK_ARG(M > 0 && N > 0 && K > 0, PPF_ERR_SHAPE, "ppf_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     PPF_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && (N % 4) == 0, PPF_ERR_ALIGN,
                   "ppf_gemm_bf16: lda/ldb must be multiples of 8, ldc and N of 4 (lda=%d ldb=%d ldc=%d N=%d)", lda, ldb, ldc, N);
@@ -303,7 +347,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
-    p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha;
+    p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha; p.ws = nullptr;
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
@@ -325,7 +369,19 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
         }
     } else {
         switch (epi) {
-            case EPI_ATOMIC: return launch<true, true, EPI_ATOMIC, true>(p, pick_splitk(M, N, K), stream);
+            case EPI_ATOMIC: {
+                const int ns = pick_splitk(M, N, K);
+                const size_t need = (size_t)ns * ((size_t)M * N + M) * sizeof(float);
+                if (workspace == nullptr || workspace_bytes < need || ns == 1) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
+                p.ws = (float*)workspace;
+                int rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
+                if (rc) return rc;
+                const size_t work = (size_t)M * N / 4 + (colsum ? M : 0);
+                const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns);
+                PPF_LAUNCH_CHECK();
+                return 0;
+            }
             case EPI_F32: return launch<true, true, EPI_F32, false>(p, 1, stream);
             default: break;
         }

@@ -197,57 +197,100 @@ __device__ __forceinline__ float grad_d(const ProtoBwdParams& p, int b, int pi, 
     return g * dact_dd(p.dist_full[o], p.act_kind, p.eps);
 }
 
-// One workgroup per sample.  Phase 1: all waves stream the sample's (P,T) gradient rows (token-contiguous,
-// coalesced) and mark the non-zero dL/dd entries in an LDS bitmap [T][P bits] (order-independent atomic OR).
-// Phase 2: wave w owns tokens w, w+NW, ... and walks its bitmap row in ascending prototype order, so every
-// token gradient is accumulated in a fixed order (deterministic) from exact fp32 (x - p) differences.
-template <int NJ>
-__global__ __launch_bounds__(1024) void proto_bwd_tokens_kernel(const ProtoBwdParams p) {
-    constexpr int NW = 16;
-    extern __shared__ uint32_t bm[];                  // [T][W]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x;
-    const int W = (p.P + 31) / 32;
-    for (int i = threadIdx.x; i < p.T * W; i += 1024) bm[i] = 0;
-    __syncthreads();
-    for (int pi = wave; pi < p.P; pi += NW) {
-        const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
-        const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
-        for (int tb = 0; tb < p.T; tb += 64) {
-            const int t = tb + lane;
-            if (t < p.T && grad_d(p, b, pi, t, am, gm) != 0.f) atomicOr(&bm[t * W + (pi >> 5)], 1u << (pi & 31));
+// Token gradients in two fully parallel passes (deterministic, no float atomics):
+//  mark  : stream the (B,P,T) upstream gradient once (coalesced) and set bit (b,t,p) of a global bitmap [B][T][W]
+//          wherever dL/dd != 0 (order-independent atomic OR)
+//  gather: one wavefront per token (b,t) walks its bitmap row in ascending prototype order and accumulates
+//          2 G (x - p) in exact fp32 -- ~35 non-zeros per token, latency hidden by ~20k independent waves.
+__global__ __launch_bounds__(256) void proto_bwd_mark_kernel(const ProtoBwdParams p, uint32_t* __restrict__ bm, int W) {
+    const size_t total = (size_t)p.B * p.P * p.T;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int t = (int)(e % p.T);
+        const size_t bp = e / p.T;
+        float g = p.g_full ? p.g_full[e] : 0.f;
+        if (p.g_max) {
+            const int am = p.argmax ? p.argmax[bp] : 0;
+            if (t == am) g += p.g_max[bp];
+        }
+        if (g != 0.f && dact_dd(p.dist_full[e], p.act_kind, p.eps) != 0.f) {
+            const int b = (int)(bp / p.P), pi = (int)(bp % p.P);
+            atomicOr(&bm[((size_t)b * p.T + t) * W + (pi >> 5)], 1u << (pi & 31));
         }
     }
-    __syncthreads();
-    for (int t = wave; t < p.T; t += NW) {
-        const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + t) * p.Dp;
-        float x[NJ], acc[NJ];
+}
+
+// One 8-wave workgroup per token (b,t): wave w owns an eighth of the prototype axis.  The arg-max routing piles most
+// prototypes of a sample onto a few tokens, so a token's non-zeros are (1) compacted per wave into an ascending LDS list,
+// (2) their dL/dd evaluated 64 at a time across the lanes (all gathers in flight together), (3) applied as
+// 2 G (x - p) row updates four prototype rows per step, and (4) the eight partial rows reduced through LDS in fixed order.
+template <int NJ>
+__global__ __launch_bounds__(512) void proto_bwd_tokens_kernel(const ProtoBwdParams p, const uint32_t* __restrict__ bm, int W) {
+    constexpr int NW = 8;
+    __shared__ unsigned short plist[NW][8 * 32 * 4];       // up to 32 words per wave (P <= 8192)
+    __shared__ float part[NW][NJ * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x;                            // (b, t)
+    const int b = row / p.T, t = row % p.T;
+    const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + t) * p.Dp;
+    float x[NJ], acc[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; x[j] = d < p.Dp ? xrow[d] : 0.f; acc[j] = 0.f; }
-        for (int w0 = 0; w0 < W; w0 += 64) {
-            const uint32_t mine = (w0 + lane < W) ? bm[t * W + w0 + lane] : 0u;
-            unsigned long long lanes = __ballot(mine != 0u);
-            while (lanes) {
-                const int src = __builtin_ctzll(lanes);
-                lanes &= lanes - 1;
-                uint32_t word = __shfl(mine, src, 64);
-                while (word) {
-                    const int bit = __builtin_ctz(word);
-                    word &= word - 1;
-                    const int pi = (w0 + src) * 32 + bit;
-                    const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
-                    const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
-                    const float g2 = 2.0f * grad_d(p, b, pi, t, am, gm);
-                    const float* prow = p.protos + (size_t)pi * p.Dp;
+    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; x[j] = d < p.Dp ? xrow[d] : 0.f; acc[j] = 0.f; }
+    const int wpw = (W + NW - 1) / NW;                     // words per wave (<= 32)
+    const int w_begin = wave * wpw, w_end = min(W, w_begin + wpw);
+    // (1) ascending list of this wave's prototypes with a non-zero gradient for this token
+    const uint32_t mine = (w_begin + lane < w_end) ? bm[(size_t)row * W + w_begin + lane] : 0u;
+    const int cnt = __popc(mine);
+    int incl = cnt;
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (x[j] - prow[d]); }
-                }
-            }
+    for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+    const int total = __shfl(incl, 63, 64);
+    {
+        int pos = incl - cnt;
+        uint32_t word = mine;
+        while (word) { const int bit = __builtin_ctz(word); word &= word - 1; plist[wave][pos++] = (unsigned short)((w_begin + lane) * 32 + bit - w_begin * 32); }
+    }
+    // (wave-private LDS region: same-wave program order makes the list visible)
+    for (int base = 0; base < total; base += 64) {
+        const int n = min(64, total - base);
+        int pi = 0; float g2 = 0.f;
+        if (lane < n) {
+            pi = w_begin * 32 + plist[wave][base + lane];
+            const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
+            const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
+            g2 = 2.0f * grad_d(p, b, pi, t, am, gm);
         }
-        float* drow = p.dtok + (size_t)b * p.dstride_b + (size_t)(p.t0 + t) * p.Dp;
+        for (int e = 0; e < n; e += 4) {
+            float gs[4]; const float* pr[4];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) drow[d] = acc[j]; }
+            for (int u = 0; u < 4; ++u) {
+                const int src = min(e + u, n - 1);
+                gs[u] = (e + u < n) ? __shfl(g2, src, 64) : 0.f;
+                pr[u] = p.protos + (size_t)__shfl(pi, src, 64) * p.Dp;
+            }
+            float v[4][NJ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; v[u][j] = d < p.Dp ? pr[u][d] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] += gs[u] * (x[j] - v[u][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) part[wave][j * 64 + lane] = acc[j];
+    __syncthreads();
+    float* drow = p.dtok + (size_t)b * p.dstride_b + (size_t)(p.t0 + t) * p.Dp;
+    for (int i = threadIdx.x; i < NJ * 64; i += 512) {
+        const int d = (i & 63) + 64 * (i >> 6);
+        if (d < p.Dp) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sacc += part[w][i];
+            drow[d] = sacc;
+        }
     }
 }
 
@@ -328,17 +371,25 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
 // dtok rows are overwritten; dprotos [P][Dp] is accumulated (+=).
 int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
                   const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok, int64_t dstride_b,
-                  float* dprotos, hipStream_t stream) {
-    PPF_CHECK_ARG(B > 0 && P > 0 && Dp > 0 && T >= 1 && Dp <= 512, PPF_ERR_SHAPE, "ppf_proto_bwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
+                  float* dprotos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && Dp > 0 && T >= 1 && Dp <= 512, PPF_ERR_SHAPE, "ppf_proto_bwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
     PPF_CHECK_ARG(tok && protos && dist_full && (g_full || g_max) && (T == 1 || argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd: null pointer");
-    PPF_CHECK_ARG((size_t)T * ((P + 31) / 32) * 4 <= 64 * 1024, PPF_ERR_SHAPE, "ppf_proto_bwd: T*P bitmap exceeds 64 KiB of LDS (T=%d P=%d)", T, P);
+    const int W = (P + 31) / 32;
+    const size_t need = (size_t)B * T * W * sizeof(uint32_t);
+    PPF_CHECK_ARG(dtok == nullptr || (workspace != nullptr && workspace_bytes >= need), PPF_ERR_ARG,
+                  "ppf_proto_bwd: needs a ZEROED workspace of B*T*ceil(P/32)*4 = %zu bytes", need);
     ProtoBwdParams p;
     p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
     p.dist_full = dist_full; p.g_full = g_full; p.g_max = g_max; p.argmax = (T == 1) ? nullptr : argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
     const int nj = (Dp + 63) / 64;
     auto run = [&](auto njc) {
         constexpr int NJ = decltype(njc)::value;
-        if (dtok) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ>), dim3(B), dim3(1024), (size_t)T * ((P + 31) / 32) * 4, stream, p);
+        if (dtok) {
+            const size_t total = (size_t)B * P * T;
+            const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+            hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(grid), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
+            hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
+        }
         if (dprotos) hipLaunchKernelGGL((proto_bwd_protos_kernel<NJ>), dim3(P), dim3(256), 0, stream, p);
     };
     if (nj <= 1) run(std::integral_constant<int, 1>());

@@ -12,6 +12,18 @@ DOMINANT_KEY = (True, True, EPI_ATOMIC)
 DOMINANT_NAME = "gemm_kernel<TA=1,TB=1,EPI_ATOMIC,COLSUM> (weight-gradient bf16 MFMA GEMM, split over the contraction)"
 
 
+_WORKSPACE = {}
+
+
+def _workspace(device, nbytes):
+    """Reusable split-K scratch (grown on demand, one per device)."""
+    buf = _WORKSPACE.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = buf
+    return buf
+
+
 def _chk(t, dtype=None):
     assert t.is_cuda and t.is_contiguous(), "kernel operands must be contiguous CUDA tensors"
     if dtype is not None:
@@ -35,13 +47,16 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
     for t in (aux_in, aux_out):
         if t is not None:
             ldaux = t.shape[-1]
+    ws = None
+    if epi == EPI_ATOMIC:
+        ws = _workspace(a.device, _lib.lib().ppf_gemm_workspace_bytes(M, N, K))
     probe = PROFILE["enabled"] and PROFILE["key"] == (bool(trans_a), bool(trans_b), epi)
     if probe:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.call("ppf_gemm_bf16", a, b, out, M, N, K, a.shape[1], b.shape[1], out.shape[-1], int(trans_a), int(trans_b), epi,
               bias, res, res.shape[-1] if res is not None else 0, rowscale, rows_per_group, colscale, aux_in, aux_out, ldaux,
-              colsum, float(alpha))
+              colsum, float(alpha), ws, ws.numel() if ws is not None else 0)
     if probe:
         e1.record()
         PROFILE["events"].append((e0, e1))
@@ -160,8 +175,9 @@ def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_
 def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4):
     B, Ttot, Dp = tokens.shape
     P = protos.shape[0]
+    bitmap = torch.zeros((B, T, (P + 31) // 32), dtype=torch.int32, device=tokens.device) if dtok is not None else None
     _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_full, g_max, argmax, dtok,
-              Ttot * Dp, dprotos)
+              Ttot * Dp, dprotos, bitmap, bitmap.numel() * 4 if bitmap is not None else 0)
 
 
 def ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh):
