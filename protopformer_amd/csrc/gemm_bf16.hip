@@ -18,11 +18,14 @@
 // output row m: 8/16-byte row-major stores and vector bias/residual accesses.
 // blockIdx is remapped XCD-aware (n-tiles of one m-panel share an XCD's L2).
 #include "ppf_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile (either mode)
+constexpr int STAGE_LD = 68;                     // fp32 pitch of the per-wave epilogue strip (64 + 4: conflict-free float4 rows)
+constexpr int STAGE_BYTES = 4 * 32 * STAGE_LD * 4;   // 4 waves x 32 rows
 
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_SIGMOID_F32 = 3, EPI_RESID = 4, EPI_DGELU = 5, EPI_ATOMIC = 6, EPI_PARTIAL = 7 };
 
@@ -159,8 +162,8 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
     }
 }
 
-template <bool TA, bool TB, int EPI, bool COLSUM>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+template <bool TA, bool TB, int EPI, bool COLSUM, bool DBUF>
+__global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = DBUF ? (kt & 1) : 0;
         const unsigned char* tA = smem + buf * 2 * TILE_BYTES;
         const unsigned char* tB = tA + TILE_BYTES;
         const bool more = (kt + 1) < nk;
@@ -233,32 +236,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
                 }
             }
         }
+        if constexpr (!DBUF) __syncthreads();               // single LDS buffer: everyone finished reading it
         if (more) {
-            unsigned char* nA = smem + (buf ^ 1) * 2 * TILE_BYTES;
+            unsigned char* nA = smem + (DBUF ? (buf ^ 1) : 0) * 2 * TILE_BYTES;
             TileIO<TA>::sstore(ra, nA, tid);
             TileIO<TB>::sstore(rb, nA + TILE_BYTES, tid);
         }
         __syncthreads();
     }
 
-    // epilogue: lane holds, for each (ni, mi): row m = m0+wm+32*mi+(lane&31), and for g = 0..3 the four
-    // consecutive columns n = n0+wn+32*ni+8*g+4*(lane>>5) .. +3  (acc regs 4g..4g+3)
+    // epilogue.  After the MFMAs a lane holds, for each (ni, mi): row m = wm+32*mi+(lane&31) and, for g = 0..3, the four
+    // consecutive columns n = wn+32*ni+8*g+4*(lane>>5).. (acc regs 4g..4g+3): row-strided 8/16-byte pieces.  Each wave
+    // therefore transposes its accumulators through a private LDS strip (32 rows x 64 fp32 at a time) so that 16
+    // consecutive lanes cover one 64-column row segment: bias / residual reads and the output stores become full
+    // 128/256-byte runs.  (The main loop's last barrier has already retired every read of the operand tiles.)
     const int h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * STAGE_LD);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm + 32 * mi + (lane & 31);
-        if (m >= p.M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn + 32 * ni + 8 * g + 4 * h;
-                if (n < p.N)
-                    epilogue4<EPI>(p, m, n, acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
+                    make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+        const int col = (lane & 15) * 4;
+        const int n = n0 + wn + col;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 4 + (lane >> 4);
+            const int m = m0 + wm + 32 * mi + r;
+            const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
+            if (m < p.M && n < p.N) epilogue4<EPI>(p, m, n, v.x, v.y, v.z, v.w);
         }
         if constexpr (COLSUM) {
-            if (do_colsum && h == 0) {
+            const int m = m0 + wm + 32 * mi + (lane & 31);
+            if (do_colsum && h == 0 && m < p.M) {
                 if constexpr (EPI == EPI_PARTIAL) p.ws[blockIdx.z * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
                 else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
             }
@@ -266,19 +279,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <bool TA, bool TB, int EPI, bool COLSUM>
-int launch(const GemmParams& p, int splitk, hipStream_t stream) {
+template <bool TA, bool TB, int EPI, bool COLSUM, bool DBUF>
+int launch_impl(const GemmParams& p, int splitk, hipStream_t stream) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    auto kern = gemm_kernel<TA, TB, EPI, COLSUM>;
+    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, DBUF>;
+    constexpr int lds = ((DBUF ? 4 : 2) * TILE_BYTES) > STAGE_BYTES ? ((DBUF ? 4 : 2) * TILE_BYTES) : STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, splitk), dim3(NTHREADS), 4 * TILE_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splitk), dim3(NTHREADS), lds, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;
+}
+
+template <bool TA, bool TB, int EPI, bool COLSUM>
+int launch(const GemmParams& p, int splitk, hipStream_t stream) {
+    // default: single LDS operand buffer (32 KiB) -> 3 workgroups/CU; PPF_GEMM_DBUF=1 selects the double-buffered variant
+    // (one barrier per K tile, 2 workgroups/CU), measured 8-15 % slower at this model's shapes (profiles/r1_gemm_ab.txt)
+    static const bool single = !(getenv("PPF_GEMM_DBUF") != nullptr && getenv("PPF_GEMM_DBUF")[0] == '1');
+    return single ? launch_impl<TA, TB, EPI, COLSUM, false>(p, splitk, stream) : launch_impl<TA, TB, EPI, COLSUM, true>(p, splitk, stream);
 }
 
 // out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the M partial column sums

@@ -60,9 +60,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): one exp + one rcp + 5 FMAs instead of libm's erff polynomial
+// ladder (the GELU epilogues were VALU-bound on it).  ex2 = exp(-x*x) is returned for reuse by the GELU derivative.
+__device__ __forceinline__ float fast_erf(float x, float& ex2) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    ex2 = __expf(-ax * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return copysignf(1.0f - poly * ex2, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float e;
+    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f, e));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    float e;                                                   // e = exp(-x^2/2)
+    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f, e));
+    return cdf + x * 0.39894228040143267794f * e;
 }
 
 // Bijective XCD-aware remap of a 1-D block id: consecutive virtual ids land on the same XCD (private L2).
