@@ -71,10 +71,10 @@ __device__ __forceinline__ int reg_row(int r, int h) { return (r & 3) + 8 * (r >
 // Stage `rows` rows (HD bf16 each) from src (row stride ld) into a swizzled LDS tile.  Rows beyond nvalid are
 // zero-filled, or (CLAMP) replicate the last valid row so that padded keys produce finite scores that never
 // exceed the true row maximum (they are then removed by keep = 0).
-template <int HD, bool CLAMP>
+template <int HD, bool CLAMP, int NTHR = 256>
 __device__ __forceinline__ void stage_rows(unsigned char* tile, const bf16_t* src, int ld, int row_begin, int rows, int nvalid, int tid) {
     constexpr int CH = HD / 8;
-    for (int i = tid; i < rows * CH; i += 256) {
+    for (int i = tid; i < rows * CH; i += NTHR) {
         const int r = i / CH, c = i - r * CH;
         uint4 v = make_uint4(0, 0, 0, 0);
         int gr = row_begin + r;
@@ -84,9 +84,14 @@ __device__ __forceinline__ void stage_rows(unsigned char* tile, const bf16_t* sr
     }
 }
 
+// One workgroup per (batch, head): K/V are staged ONCE and shared by all query tiles (8 waves when N > 128: the kernels are
+// bound by the K/V/Q traffic and its latency, not by the MFMAs -- profiles/r1_step1_kernel_stats.txt).
+template <int NT> struct Geo { static constexpr int NW = NT > 4 ? 8 : 4, NTHR = NW * 64; };
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD, int NT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + NT * 32 * 4];
     unsigned char* tK = lds;
     unsigned char* tV = lds + NT * 32 * 128;
@@ -96,11 +101,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
     const float c = SOFTMAX_EPS / (float)N;
-    stage_rows<HD, true>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
-    stage_rows<HD, false>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
-    for (int i = tid; i < NT * 32; i += 256) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+    stage_rows<HD, true, NTHR>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
+    stage_rows<HD, false, NTHR>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
+    for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
     __syncthreads();
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
     if (q0 >= N) return;
     const int q = q0 + (lane & 31), qc = min(q, N - 1);
     const int qself = p.self_keep ? q : -1;
@@ -247,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void attn_headmean_kernel(const AttnParams 
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <int HD, int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + NT * 32 * 4];
     unsigned char* tK = lds;
     unsigned char* tV = lds + NT * 32 * 128;
@@ -256,11 +262,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    stage_rows<HD, true>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
-    stage_rows<HD, false>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
-    for (int i = tid; i < NT * 32; i += 256) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+    stage_rows<HD, true, NTHR>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
+    stage_rows<HD, false, NTHR>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
+    for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
     __syncthreads();
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
     if (q0 >= N) return;
     const int q = q0 + (lane & 31), qc = min(q, N - 1);
     const int qself = p.self_keep ? q : -1;
@@ -333,7 +339,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 
 // --------------------------------------------------------------------------------------- backward: dK, dV
 template <int HD, int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
+    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + 3 * NT * 32 * 4];
     unsigned char* tQ = lds;
     unsigned char* tO = lds + NT * 32 * 128;
@@ -344,16 +351,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnParams p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    stage_rows<HD, false>(tQ, base, p.ld, 0, NT * 32, N, tid);
-    stage_rows<HD, false>(tO, p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, NT * 32, N, tid);
-    for (int i = tid; i < NT * 32; i += 256) {
+    stage_rows<HD, false, NTHR>(tQ, base, p.ld, 0, NT * 32, N, tid);
+    stage_rows<HD, false, NTHR>(tO, p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, NT * 32, N, tid);
+    for (int i = tid; i < NT * 32; i += NTHR) {
         const size_t si = ((size_t)b * p.H + h) * N + i;
         st_m[i] = i < N ? p.rowmax[si] : 0.f;
         st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
         st_d[i] = i < N ? p.delta[si] : 0.f;
     }
     __syncthreads();
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = (blockIdx.x * NW + wave) * 32;
     if (k0 >= N) return;
     const int key = k0 + (lane & 31), kc = min(key, N - 1);
     const float keep_key = key < N ? (p.policy ? p.policy[(size_t)b * N + kc] : 1.0f) : 0.f;
@@ -460,7 +467,8 @@ int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax,
     if (rc) return rc;
     p.out = (bf16_t*)out;
     return dispatch(D / H, N, "ppf_attn_fwd", [&](auto hd, auto nt) {
-        hipLaunchKernelGGL((attn_fwd_kernel<decltype(hd)::value, decltype(nt)::value>), dim3((N + 127) / 128, H, B), dim3(256), 0, stream, p);
+        using G = Geo<decltype(nt)::value>;
+        hipLaunchKernelGGL((attn_fwd_kernel<decltype(hd)::value, decltype(nt)::value>), dim3((N + G::NW * 32 - 1) / (G::NW * 32), H, B), dim3(G::NTHR), 0, stream, p);
         PPF_LAUNCH_CHECK();
         return 0;
     });
@@ -494,10 +502,11 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
-        dim3 grid((N + 127) / 128, H, B);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(256), 0, stream, p);
+        using G = Geo<decltype(nt)::value>;
+        dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(G::NTHR), 0, stream, p);
         PPF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(G::NTHR), 0, stream, p);
         PPF_LAUNCH_CHECK();
         return 0;
     });
