@@ -69,6 +69,20 @@ def cpu_baseline(batch=16, steps=2):
             "sample": f"{steps} fp32 train steps of {ARCH}+{P}x{DP} protos at batch {batch} (oracle/ppf_oracle.py, torch CPU, {threads} threads)"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/r1_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction applied)."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        for name, v in ks.items():
+            if "gemm_kernel<true, true, 7" in name:
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +117,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # roofline probe: HIP events around every launch of the dominant kernel (wgrad GEMM) on its launch stream
-    ops.PROFILE.update(enabled=True, key=ops.DOMINANT_KEY, events=[], flops=0.0)
+    ops.PROFILE.update(enabled=True, key=ops.DOMINANT_KEY, events=[], flops=0.0, bytes=0.0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,7 +146,8 @@ def main():
                                    "train step = fwd+CE+PPC+bwd+allreduce+AdamW+EMA, DropPath 0.1", "global_batch": world * args.batch,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": ops.DOMINANT_NAME, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "launches": n_launch,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(), "traffic_unit": "bytes/launch (PMC, see profiles/r1_pmc_traffic.json)",
+                         "algorithmic_bytes": ops.PROFILE["bytes"] / max(n_launch, 1), "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1)},
             "step_mfma_frac": (ips / world) * TRAIN_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
             "final_loss": float(loss),

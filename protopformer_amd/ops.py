@@ -7,7 +7,7 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_SIGMOID_F32, EPI_RESID, EPI_DGELU, EPI_ATOMIC =
 
 
 # bench.py's roofline probe: HIP events (on the launch stream) around every launch of one GEMM instantiation
-PROFILE = dict(enabled=False, key=None, events=[], flops=0.0)
+PROFILE = dict(enabled=False, key=None, events=[], flops=0.0, bytes=0.0)
 DOMINANT_KEY = (True, True, EPI_ATOMIC)
 DOMINANT_NAME = "gemm_kernel<TA=1,TB=1,EPI_ATOMIC,COLSUM> (weight-gradient bf16 MFMA GEMM, split over the contraction)"
 
@@ -61,6 +61,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
         e1.record()
         PROFILE["events"].append((e0, e1))
         PROFILE["flops"] += 2.0 * M * N * K
+        PROFILE["bytes"] += 2.0 * (M * K + N * K) + out.element_size() * M * N      # operands read once + output written once
     return out
 
 
