@@ -51,6 +51,13 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
 /* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic two-pass reduction instead of atomics) */
 size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
+/* nbatch = batch_outer*batch_inner plain GEMMs; problem (o,i) uses A + o*sa_o + i*sa_i (elements), same for B / C.
+ * kpad = 1: contraction-contiguous operands may read the (zero) padding up to the next multiple of 8 beyond K.
+ * CaiT talking-heads attention per-(sample, head) products: A.V, dO.V^T, dS.K, dS^T.Q, A^T.dO (cait:128-130 and autograd). */
+int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                          int trans_b, int out_f32, float alpha, int batch_outer, int batch_inner, int64_t sa_o, int64_t sa_i,
+                          int64_t sb_o, int64_t sb_i, int64_t sc_o, int64_t sc_i, int kpad, ppf_stream_t stream);
+
 /* ---- LayerNorm (deit:67,72,238 norm1/norm2/norm, eps 1e-6) ----------------------------------------------------
  * fwd: y bf16 [rows][D] = LN(x fp32 [row_map ? row_map[r] : r][D]); saves mean / rstd per output row.
  * bwd: dx_out[src] = dres_in[src] + LN'(dy); dw/db accumulate.  Optional fused pass for the residual branch below:
@@ -73,6 +80,24 @@ int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax,
                       int B, int H, int N, int D, int self_keep, ppf_stream_t stream);
 int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, const float* policy, const float* rowmax,
                  const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, ppf_stream_t stream);
+
+/* ---- CaiT: talking-heads self-attention (cait:93-132) and class attention (cait:34-90) --------------------------------
+ * th_scores: sp[b][g][q][key] = sum_h Wl[g][h]*(scale q_h.k_h) + bl[g];  th_softmax_mix (in place): sp <- softmax(sp),
+ * a16 = bf16(proj_w(P)) [B][H][N][NPK], hm = mean over heads of proj_w(P) [B][N][NP] (rollout input, cait:228).
+ * th_softmax_bwd: da (in dA, out dS'), ds16 = bf16(Wl^T dS'), dww/dbw/dbl +=;  th_dwl: dWl += sum dS' * raw scores. */
+int ppf_th_scores(const void* qkv, const float* wl, const float* bl, float* sp, int B, int H, int N, int D, int NP, ppf_stream_t stream);
+int ppf_th_dwl(const void* qkv, const float* ds_prime, float* dwl, int B, int H, int N, int D, int NP, ppf_stream_t stream);
+int ppf_th_softmax_mix(float* sp, void* a16, float* hm, const float* ww, const float* bw, int B, int H, int N, int NP, int NPK,
+                       ppf_stream_t stream);
+int ppf_th_softmax_bwd(const float* prob, float* da, void* ds16, const float* ww, const float* wl, float* dww, float* dbw, float* dbl,
+                       int B, int H, int N, int NP, int NPK, ppf_stream_t stream);
+/* class attention: q [B][D] (cls rows, unscaled), k/v [B*N1][D] bf16; policy softmax WITHOUT the identity term (cait:58-59) */
+int ppf_class_attn_fwd(const void* q, const void* k, const void* v, const float* policy, float* attn, float* zinv, float* rowmean,
+                       void* out, int B, int H, int N1, int D, ppf_stream_t stream);
+int ppf_class_attn_bwd(const void* q, const void* k, const void* v, const float* attn, const float* zinv, const void* dout, void* dq,
+                       void* dk, void* dv, int B, int H, int N1, int D, ppf_stream_t stream);
+/* out bf16 [rows][D] = a + b (+ cq[row / N1] where row % N1 == 0): input gradient of the class-attention q/k/v projections */
+int ppf_merge3_cast(const float* a, const float* b, const float* cq, void* out, int rows, int D, int N1, ppf_stream_t stream);
 
 /* ---- attention rollout + token reservation (deit:99-124, 223-234; cait:223-261, 328-339) ------------------------
  * hm [L][B][N][NP] head-mean attention of the rollout layers; kdrop = int(N*N*0.9), kdrop_init = int((N+1)*0.9).

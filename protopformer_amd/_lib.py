@@ -32,6 +32,14 @@ SIGS = {
     "ppf_sgemm": "ppp" "iii" "llll" "i" "ff" "s",
     "ppf_axpby": "ppp" "ff" "l" "s",
     "ppf_topk_sorted": "piiips",
+    "ppf_gemm_bf16_batched": "ppp" "iiiiii" "iii" "f" "ii" "llllll" "i" "s",
+    "ppf_th_scores": "pppp" "iiiii" "s",
+    "ppf_th_dwl": "ppp" "iiiii" "s",
+    "ppf_th_softmax_mix": "ppppp" "iiiii" "s",
+    "ppf_th_softmax_bwd": "pppppppp" "iiiii" "s",
+    "ppf_class_attn_fwd": "pppppppp" "iiii" "s",
+    "ppf_class_attn_bwd": "ppppppppp" "iiii" "s",
+    "ppf_merge3_cast": "pppp" "iii" "s",
     "ppf_sigmoid_bwd": "ppppiis",
 }
 
@@ -60,7 +68,7 @@ def lib():
 def _ptr(x):
     if x is None:
         return None
-    if isinstance(x, torch.Tensor):
+    if isinstance(x, torch.Tensor) or hasattr(x, "data_ptr"):
         return x.data_ptr()
     return x
 

@@ -1,0 +1,304 @@
+"""CaiT backbone of ProtoPFormer on the HIP kernels (host-side orchestration only).
+
+Mirrors the reference's ``MyCait`` (tools/cait_models_attn.py:188-345): 24 LayerScale blocks with talking-heads attention on the
+patch tokens, then 2 class-attention blocks that update only the cls token, attention rollout + token reservation before class
+block ``reserve_layer`` (cait:326-339).  Parameter names equal the reference's (``blocks.{i}.{gamma_1,gamma_2,norm1,attn.{qkv,proj,
+proj_l,proj_w},norm2,mlp.{fc1,fc2}}``, ``blocks_token_only.{i}.{gamma_1,gamma_2,norm1,attn.{q,k,v,proj},norm2,mlp}``, ``pos_embed``
+``(1,Np,D)``, ``cls_token``, ``norm``).  nn modules are parameter containers only; all arithmetic is in csrc/cait.hip + the GEMMs.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbone import LN_EPS, _dp, _wgrad, head_tokens_fwd
+from .deit import _Mlp, _PatchEmbed, _init_vit
+from .ops import EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID
+
+
+class _TalkingHeadAttn(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_l = nn.Linear(num_heads, num_heads)
+        self.proj_w = nn.Linear(num_heads, num_heads)
+
+
+class _ClassAttn(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.q = nn.Linear(dim, dim, bias=True)
+        self.k = nn.Linear(dim, dim, bias=True)
+        self.v = nn.Linear(dim, dim, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class LayerScaleBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, drop_path, init_values, attn_cls):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.attn = attn_cls(dim, num_heads)
+        self.drop_path_rate = float(drop_path)
+        self.norm2 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.gamma_1 = nn.Parameter(init_values * torch.ones(dim))
+        self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
+
+
+class MyCait(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=192, depth=24, num_heads=4, mlp_ratio=4., drop_path_rate=0.1,
+                 init_scale=1e-5, depth_token_only=2, **_unused):
+        super().__init__()
+        self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
+        self.layer_nums = [depth, depth_token_only]
+        self.patch_embed = _PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+        self.blocks = nn.ModuleList([LayerScaleBlock(embed_dim, num_heads, mlp_ratio, drop_path_rate, init_scale, _TalkingHeadAttn)
+                                     for _ in range(depth)])                                         # constant rate (cait:206)
+        self.blocks_token_only = nn.ModuleList([LayerScaleBlock(embed_dim, num_heads, 4.0, 0.0, init_scale, _ClassAttn)
+                                                for _ in range(depth_token_only)])
+        self.norm = nn.LayerNorm(embed_dim, eps=LN_EPS)
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.apply(_init_vit)
+
+    def droppath_rates(self):
+        return [r for blk in self.blocks for r in (blk.drop_path_rate, blk.drop_path_rate)]
+
+    def __repr__(self):
+        return "MyCait(hip)" + super().__repr__()[len("MyCait"):]
+
+    def _store(self):
+        root = getattr(self, "_ppf_root", None)
+        if root is None:
+            raise RuntimeError("features module must be owned by a protopformer_amd.PPNet (flat parameter store)")
+        return root().flat_store()
+
+    @torch.no_grad()
+    def forward_feature_patch_embed_all(self, x):
+        """cait:303-312 (inference-only compatibility wrapper): returns (cls_tokens [B,1,D], x [B,Np,D])."""
+        xe = cait_embed(self, self._store(), x)
+        return self.cls_token.expand(x.shape[0], -1, -1), xe
+
+    @torch.no_grad()
+    def forward_feature_mask_train_direct(self, cls_embed, x_embed, token_attn=None, reserve_layer_nums=[]):
+        """cait:314-345 (inference-only compatibility wrapper)."""
+        (layer, k), = reserve_layer_nums
+        u, cls_attn, idx, _ = cait_blocks_fwd(self, self._store(), x_embed.contiguous(), layer, k, dp=None, save=False)
+        B, N1, D = u.shape
+        y, _, _ = ops.layernorm_fwd(u.reshape(B * N1, D), self.norm.weight, self.norm.bias, LN_EPS)
+        return y.float().reshape(B, N1, D), (cls_attn, None)
+
+
+# ------------------------------------------------------------------------------------------------ forward
+def cait_embed(feats, store, img, saved=None):
+    pe = feats.patch_embed
+    B, D, Np = img.shape[0], feats.embed_dim, pe.num_patches
+    cols = ops.im2col_patch(img.contiguous().float(), pe.patch_size)
+    tok = ops.gemm(cols, store.w16(pe.proj.weight).reshape(D, -1), epi=EPI_F32, bias=pe.proj.bias)
+    x = ops.assemble_tokens(tok, feats.cls_token, feats.pos_embed, B, Np, D, 0)          # cls gets no position (cait:307-309)
+    if saved is not None:
+        saved["cols"] = cols
+    return x
+
+
+def _th_attention_fwd(blk, qkv, B, H, N, D, hm_slot):
+    """Talking-heads attention (cait:115-130) from packed qkv; returns (out bf16 [B*N,D], P fp32, A bf16)."""
+    hd = D // H
+    sp = ops.th_scores(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, B, H, N, D)
+    a16 = ops.th_softmax_mix(sp, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot)      # sp now holds P
+    NPK = a16.shape[-1]
+    ao = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
+    # O_h[q][d] = sum_key A_h[q][key] V_h[key][d]
+    ops.gemm_batched(a16, ops._Off(qkv, 2 * D), ao, N, hd, N, NPK, 3 * D, D, False, True, False, 1.0, B, H,
+                     (H * N * NPK, N * NPK), (N * 3 * D, hd), (N * D, hd), kpad=1)
+    return ao, sp, a16
+
+
+def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
+    """24 talking-heads blocks + class-attention blocks with rollout/reservation (cait:314-345).
+    x fp32 [B,Np,D] -> (u_out [B,1+Np,D] fp32 = cat(cls, x), cls_token_attn [B,Np], idx int32 [B,k], saved)."""
+    B, N, D = x.shape
+    H = feats.num_heads
+    M = B * N
+    NP = (N + 3) // 4 * 4
+    depth = len(feats.blocks)
+    hm = torch.empty((depth, B, N, NP), dtype=torch.float32, device=x.device)
+    layers = []
+    x = x.reshape(M, D)
+    for i, blk in enumerate(feats.blocks):
+        n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
+        ao, prob, a16 = _th_attention_fwd(blk, qkv, B, H, N, D, hm[i])
+        s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
+        raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
+        x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N,
+                      colscale=blk.gamma_1, aux_out=raw1)
+        n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
+        g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
+        raw2 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
+        x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=N,
+                      colscale=blk.gamma_2, aux_out=raw2)
+        if save:
+            layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, prob=prob, a16=a16, ao=ao, x1=x1, n2=n2, mean2=mean2,
+                               rstd2=rstd2, h=h, g=g, raw1=raw1, raw2=raw2, s1=s1, s2=s2))
+        x = x2
+    # ---- class-attention stage: only the cls token changes
+    N1 = N + 1
+    cls = feats.cls_token.detach().reshape(1, D).expand(B, D).contiguous()
+    xt = x.reshape(B, N, D)
+    policy = cls_attn = idx = None
+    ca_layers, rowmeans = [], []
+    for j, blk in enumerate(feats.blocks_token_only):
+        if j == reserve_layer:
+            init_rows = torch.stack(rowmeans).contiguous()                       # class-attention rows produced so far (cait:249-251)
+            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows)
+        u = torch.cat([cls.reshape(B, 1, D), xt], dim=1).reshape(B * N1, D)
+        n, mean1, rstd1 = ops.layernorm_fwd(u, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        kk = ops.gemm(n, store.w16(blk.attn.k.weight), epi=EPI_BF16, bias=blk.attn.k.bias)
+        vv = ops.gemm(n, store.w16(blk.attn.v.weight), epi=EPI_BF16, bias=blk.attn.v.bias)
+        ncls = n.reshape(B, N1 * D)[:, :D]                                       # cls rows of n: row stride N1*D
+        qq = torch.empty((B, D), dtype=torch.bfloat16, device=x.device)
+        ops._lib.call("ppf_gemm_bf16", n, store.w16(blk.attn.q.weight), qq, B, D, D, N1 * D, D, D, 0, 0, EPI_BF16, blk.attn.q.bias, None, 0,
+                      None, 1, None, None, None, 0, None, 1.0, None, 0)
+        out, attn, zinv, rowmean = ops.class_attn_fwd(qq, kk, vv, policy, B, H, N1, D)
+        rowmeans.append(rowmean)
+        raw1 = torch.empty((B, D), dtype=torch.bfloat16, device=x.device) if save else None
+        cls1 = ops.gemm(out, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=cls, colscale=blk.gamma_1, aux_out=raw1)
+        n2, mean2, rstd2 = ops.layernorm_fwd(cls1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        h = torch.empty((B, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
+        g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
+        raw2 = torch.empty((B, D), dtype=torch.bfloat16, device=x.device) if save else None
+        cls2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=cls1, colscale=blk.gamma_2, aux_out=raw2)
+        if save:
+            ca_layers.append(dict(u=u, n=n, mean1=mean1, rstd1=rstd1, q=qq, k=kk, v=vv, attn=attn, zinv=zinv, out=out, cls=cls, cls1=cls1,
+                                  n2=n2, mean2=mean2, rstd2=rstd2, h=h, g=g, raw1=raw1, raw2=raw2, policy=policy))
+        cls = cls2
+    u_out = torch.cat([cls.reshape(B, 1, D), xt], dim=1)
+    return u_out, cls_attn, idx, dict(sa=layers, ca=ca_layers)
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
+    """Backward of the talking-heads attention: returns dqkv bf16 [B*N, 3D]; accumulates proj_l / proj_w grads."""
+    hd = D // H
+    qkv, prob, a16 = L["qkv"], L["prob"], L["a16"]
+    NP, NPK = prob.shape[-1], a16.shape[-1]
+    dev = qkv.device
+    scale = hd ** -0.5
+    dqkv = torch.empty_like(qkv)
+    # dA_h[q][key] = sum_d dO_h[q][d] V_h[key][d]
+    da = torch.empty((B, H, N, NP), dtype=torch.float32, device=dev)
+    ops.gemm_batched(dao, ops._Off(qkv, 2 * D), da, N, N, hd, D, 3 * D, NP, False, False, True, 1.0, B, H,
+                     (N * D, hd), (N * 3 * D, hd), (H * N * NP, N * NP))
+    # dV_h[key][d] = sum_q A_h[q][key] dO_h[q][d]
+    ops.gemm_batched(a16, dao, ops._Off(dqkv, 2 * D), N, hd, N, NPK, D, 3 * D, True, True, False, 1.0, B, H,
+                     (H * N * NPK, N * NPK), (N * D, hd), (N * 3 * D, hd), kpad=1)
+    ds16 = ops.th_softmax_bwd(prob, da, blk.attn.proj_w.weight, blk.attn.proj_l.weight, store.grad_view(blk.attn.proj_w.weight),
+                              store.grad_view(blk.attn.proj_w.bias), store.grad_view(blk.attn.proj_l.bias))
+    ops.th_dwl(qkv, da, store.grad_view(blk.attn.proj_l.weight), B, H, N, D)                # da now holds dS'
+    # dQ_h = scale * dS_h K_h ;  dK_h = scale * dS_h^T Q_h
+    ops.gemm_batched(ds16, ops._Off(qkv, D), dqkv, N, hd, N, NPK, 3 * D, 3 * D, False, True, False, scale, B, H,
+                     (H * N * NPK, N * NPK), (N * 3 * D, hd), (N * 3 * D, hd), kpad=1)
+    ops.gemm_batched(ds16, qkv, ops._Off(dqkv, D), N, hd, N, NPK, 3 * D, 3 * D, True, True, False, scale, B, H,
+                     (H * N * NPK, N * NPK), (N * 3 * D, hd), (N * 3 * D, hd), kpad=1)
+    return dqkv
+
+
+def _mlp_bwd(store, blk, L, dyb):
+    """Shared MLP backward: consumes dyb = bf16 gradient of the fc2 output; returns dn2 bf16."""
+    _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight)
+    dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
+    _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+    return ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
+
+
+def cait_backward(ppnet, store, saved, df):
+    feats = ppnet.features
+    sa, ca = saved["layers"]["sa"], saved["layers"]["ca"]
+    head = saved["head"]
+    u_last = saved["x_last"]                               # [B, N1, D]
+    B, N1, D = u_last.shape
+    N, H = N1 - 1, feats.num_heads
+    M = B * N
+    dev = u_last.device
+    conv = ppnet.add_on_layers[0]
+    Dp = conv.out_channels
+    gv = store.grad_view
+    dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), gv(conv.bias))
+    _wgrad(store, dz, head["nf"], conv.weight)
+    dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
+    du = torch.zeros((B * N1, D), dtype=torch.float32, device=dev)
+    ops.layernorm_bwd(dnf, u_last.reshape(B * N1, D), feats.norm.weight, head["meanf"], head["rstdf"], gv(feats.norm.weight),
+                      gv(feats.norm.bias), dx_out=du, row_map=head["row_map"])
+    du3 = du.reshape(B, N1, D)
+    dcls = du3[:, 0].contiguous()
+    # ---- class-attention blocks (reverse)
+    for j in range(len(ca) - 1, -1, -1):
+        L, blk = ca[j], feats.blocks_token_only[j]
+        dyb = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+        ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dcls, cast_out=dyb, colscale=blk.gamma_2,
+                          dbias_next=gv(blk.mlp.fc2.bias), branch=L["raw2"], dcolscale=gv(blk.gamma_2))
+        dn2 = _mlp_bwd(store, blk, L, dyb)
+        ops.layernorm_bwd(dn2, L["cls1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dcls,
+                          dx_out=dcls, cast_out=dyb, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias), branch=L["raw1"],
+                          dcolscale=gv(blk.gamma_1))
+        _wgrad(store, dyb, L["out"], blk.attn.proj.weight)
+        dout = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
+        dq, dk, dv = ops.class_attn_bwd(L["q"], L["k"], L["v"], L["attn"], L["zinv"], dout, B, H, N1, D)
+        # projections q (cls rows only), k, v
+        ncls = L["n"].reshape(B, N1 * D)[:, :D]
+        ops._lib.call("ppf_gemm_bf16", dq, L["n"], gv(blk.attn.q.weight), D, D, B, D, N1 * D, D, 1, 1, ops.EPI_ATOMIC, None, None, 0, None, 1,
+                      None, None, None, 0, gv(blk.attn.q.bias), 1.0, None, 0)
+        _wgrad(store, dk, L["n"], blk.attn.k.weight, blk.attn.k.bias)
+        _wgrad(store, dv, L["n"], blk.attn.v.weight, blk.attn.v.bias)
+        dnk = ops.gemm(dk, store.w16(blk.attn.k.weight), trans_b=True, epi=EPI_F32)
+        dnv = ops.gemm(dv, store.w16(blk.attn.v.weight), trans_b=True, epi=EPI_F32)
+        dnq = ops.gemm(dq, store.w16(blk.attn.q.weight), trans_b=True, epi=EPI_F32)
+        dn16 = ops.merge3_cast(dnk, dnv, dnq, N1)
+        du3[:, 0].copy_(dcls)                               # gradient reaching this block's cls input through the residual path
+        ops.layernorm_bwd(dn16, L["u"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=du, dx_out=du)
+        dcls = du3[:, 0].contiguous()
+    # cls_token parameter: sum over the batch of the cls gradient (column sums via the scale/cast pass)
+    scratch = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+    ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dcls, cast_out=scratch, dbias_next=gv(feats.cls_token).reshape(D))
+    # ---- talking-heads blocks (reverse)
+    dx = du3[:, 1:].contiguous().reshape(M, D)
+    dyb = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    last = feats.blocks[-1]
+    ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
+                      colscale=last.gamma_2, dbias_next=gv(last.mlp.fc2.bias), branch=sa[-1]["raw2"], dcolscale=gv(last.gamma_2))
+    gs = getattr(ppnet, "_grad_sync", None)
+    for i in range(len(sa) - 1, -1, -1):
+        L, blk = sa[i], feats.blocks[i]
+        dn2 = _mlp_bwd(store, blk, L, dyb)
+        ops.layernorm_bwd(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
+                          cast_out=dyb, rowscale=L["s1"], rows_per_group=N, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias),
+                          branch=L["raw1"], dcolscale=gv(blk.gamma_1))
+        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
+        dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
+        dqkv = _th_attention_bwd(store, blk, L, dao, B, H, N, D)
+        _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
+        dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
+        if i > 0:
+            prev, Lp = feats.blocks[i - 1], sa[i - 1]
+            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx,
+                              dx_out=dx, cast_out=dyb, rowscale=Lp["s2"], rows_per_group=N, colscale=prev.gamma_2,
+                              dbias_next=gv(prev.mlp.fc2.bias), branch=Lp["raw2"], dcolscale=gv(prev.gamma_2))
+        else:
+            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
+        if gs is not None and i in gs.block_chunk:
+            gs.chunk_ready(gs.block_chunk[i])
+    pe = feats.patch_embed
+    dtok = ops.assemble_tokens_bwd(dx, gv(feats.pos_embed).reshape(N, D), None, B, N, D, 0)
+    _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
+    if gs is not None:
+        gs.chunk_ready(gs.head_chunk)
+        gs.chunk_ready(gs.tail_chunk)
+
+
+CAIT_FNS = dict(embed=cait_embed, blocks=cait_blocks_fwd, backward=cait_backward)

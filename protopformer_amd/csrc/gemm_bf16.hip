@@ -44,6 +44,10 @@ struct GemmParams {
     float* colsum;           // EPI_ATOMIC + TA: sum over kc of A(m,kc) accumulated atomically into colsum[m]
     float* ws;               // EPI_PARTIAL: split-K workspace [nsplit][M*N (+M)] fp32 partial tiles (+ partial column sums)
     float alpha;
+    // batched problems (blockIdx.y = outer*batch_inner + inner): element offsets added to A / B / C
+    int batch_inner;
+    long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
+    int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
 };
 
 __device__ __forceinline__ int lds_off_mode0(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }
@@ -55,10 +59,10 @@ template <bool T>
 struct TileIO {
     // Issue the 4 x 16-byte global loads of this thread for the tile at (row0, k0).
     static __device__ __forceinline__ void gload(uint4 (&reg)[4], const bf16_t* __restrict__ X, int ld, int R, int row0,
-                                                 int k0, int kend, int tid) {
+                                                 int k0, int kend, int tid, int kpad = 0) {
         if constexpr (!T) {
             const int c16 = tid & 7, rb = tid >> 3;
-            const bool kok = (k0 + c16 * 8 + 8) <= kend;
+            const bool kok = kpad ? (k0 + c16 * 8) < kend : (k0 + c16 * 8 + 8) <= kend;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = row0 + rb + 32 * i;
@@ -69,7 +73,7 @@ struct TileIO {
         } else {
             const int c16 = tid & 15, kb = tid >> 4;
             const int col = row0 + c16 * 8;
-            const bool cok = (col + 8) <= R;
+            const bool cok = kpad ? col < R : (col + 8) <= R;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int kc = k0 + kb + 16 * i;
@@ -163,14 +167,22 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
 }
 
 template <bool TA, bool TB, int EPI, bool COLSUM, bool DBUF>
-__global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const GemmParams p_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_n = (p_.N + BN - 1) / BN;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (vid / tiles_n) * BM, n0 = (vid % tiles_n) * BN;
+    GemmParams p = p_;
+    if (gridDim.y > 1) {
+        const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y % p.batch_inner;
+        p.A += bo * p.sa_o + bi * p.sa_i;
+        p.B += bo * p.sb_o + bi * p.sb_i;
+        const long long co = bo * p.sc_o + bi * p.sc_i;
+        p.C = (EPI == EPI_BF16) ? (void*)(reinterpret_cast<bf16_t*>(p.C) + co) : (void*)(reinterpret_cast<float*>(p.C) + co);
+    }
 
     // contraction range of this z-slice (split-K): multiples of BK except the tail
     const int nsplit = gridDim.z;
@@ -197,8 +209,8 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
     }
     const bool do_colsum = COLSUM && p.colsum != nullptr && n0 == 0 && wn == 0;
 
-    TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
-    TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
+    TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid, p.kpad);
+    TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid, p.kpad);
     TileIO<TA>::sstore(ra, smem, tid);
     TileIO<TB>::sstore(rb, smem + TILE_BYTES, tid);
     __syncthreads();
@@ -210,8 +222,8 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
         const bool more = (kt + 1) < nk;
         if (more) {
             const int k0 = kbeg + (kt + 1) * BK;
-            TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid);
-            TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid);
+            TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
+            TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
 }
 
 template <bool TA, bool TB, int EPI, bool COLSUM, bool DBUF>
-int launch_impl(const GemmParams& p, int splitk, hipStream_t stream) {
+int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     auto kern = gemm_kernel<TA, TB, EPI, COLSUM, DBUF>;
     constexpr int lds = ((DBUF ? 4 : 2) * TILE_BYTES) > STAGE_BYTES ? ((DBUF ? 4 : 2) * TILE_BYTES) : STAGE_BYTES;
@@ -290,17 +302,17 @@ int launch_impl(const GemmParams& p, int splitk, hipStream_t stream) {
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, splitk), dim3(NTHREADS), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, nbatch, splitk), dim3(NTHREADS), lds, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;
 }
 
 template <bool TA, bool TB, int EPI, bool COLSUM>
-int launch(const GemmParams& p, int splitk, hipStream_t stream) {
+int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) {
     // default: single LDS operand buffer (32 KiB) -> 3 workgroups/CU; PPF_GEMM_DBUF=1 selects the double-buffered variant
     // (one barrier per K tile, 2 workgroups/CU), measured 8-15 % slower at this model's shapes (profiles/r1_gemm_ab.txt)
     static const bool single = !(getenv("PPF_GEMM_DBUF") != nullptr && getenv("PPF_GEMM_DBUF")[0] == '1');
-    return single ? launch_impl<TA, TB, EPI, COLSUM, false>(p, splitk, stream) : launch_impl<TA, TB, EPI, COLSUM, true>(p, splitk, stream);
+    return single ? launch_impl<TA, TB, EPI, COLSUM, false>(p, splitk, stream, nbatch) : launch_impl<TA, TB, EPI, COLSUM, true>(p, splitk, stream, nbatch);
 }
 
 // out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the M partial column sums
@@ -370,6 +382,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha; p.ws = nullptr;
+    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0;
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
@@ -409,6 +422,38 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
         }
     }
     ppf_set_error("ppf_gemm_bf16: combination trans_a=%d trans_b=%d epi=%d not instantiated", trans_a, trans_b, epi);
+    return PPF_ERR_ARG;
+}
+
+// Batched plain GEMMs (no bias / fused epilogue): nbatch = batch_outer * batch_inner problems, problem (o, i) uses
+// A + o*sa_o + i*sa_i (elements) etc.  out_f32 selects fp32 or bf16 C.  kpad = 1 lets contraction-contiguous operands read the
+// zero/finite padding up to the next multiple of 8 beyond K (K need not be a multiple of 8 then).
+// Used by the CaiT talking-heads attention: per-(sample, head) P.V, dO.V^T, dS.K, dS^T.Q, A^T.dO products.
+int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b,
+                          int out_f32, float alpha, int batch_outer, int batch_inner, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
+                          int64_t sc_o, int64_t sc_i, int kpad, hipStream_t stream) {
+    PPF_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch_outer > 0 && batch_inner > 0, PPF_ERR_SHAPE, "ppf_gemm_bf16_batched: bad shape");
+    PPF_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && (N % 4) == 0, PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: ld alignment");
+    PPF_CHECK_ARG(kpad || (trans_a ? (M % 8 == 0) : (K % 8 == 0)), PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: A inner extent must be a multiple of 8");
+    PPF_CHECK_ARG(kpad || (trans_b ? (N % 8 == 0) : (K % 8 == 0)), PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: B inner extent must be a multiple of 8");
+    PPF_CHECK_ARG(((sa_o | sa_i | sb_o | sb_i) % 8) == 0 && ((sc_o | sc_i) % 4) == 0, PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: batch strides alignment");
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.rowscale = nullptr; p.rows_per_group = 1; p.colscale = nullptr; p.aux_in = nullptr;
+    p.aux_out = nullptr; p.ldaux = 0; p.colsum = nullptr; p.ws = nullptr; p.alpha = alpha;
+    p.batch_inner = batch_inner; p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i; p.kpad = kpad;
+    const int nb = batch_outer * batch_inner;
+    const int key = (trans_a ? 4 : 0) | (trans_b ? 2 : 0) | (out_f32 ? 1 : 0);
+    switch (key) {
+        case 0: return launch<false, false, EPI_BF16, false>(p, 1, stream, nb);
+        case 1: return launch<false, false, EPI_F32, false>(p, 1, stream, nb);
+        case 2: return launch<false, true, EPI_BF16, false>(p, 1, stream, nb);
+        case 3: return launch<false, true, EPI_F32, false>(p, 1, stream, nb);
+        case 6: return launch<true, true, EPI_BF16, false>(p, 1, stream, nb);
+        case 7: return launch<true, true, EPI_F32, false>(p, 1, stream, nb);
+        default: break;
+    }
+    ppf_set_error("ppf_gemm_bf16_batched: (trans_a=1, trans_b=0) is not instantiated");
     return PPF_ERR_ARG;
 }
 

@@ -235,3 +235,72 @@ def sigmoid_bwd(df, f, dbias):
     dz = torch.empty((rows, cols), dtype=torch.bfloat16, device=f.device)
     _lib.call("ppf_sigmoid_bwd", df, f, dz, dbias, rows, cols)
     return dz
+
+
+# ------------------------------------------------------------------------------------------------ CaiT
+def gemm_batched(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_f32, alpha, bo, bi, sa, sb, sc, kpad=0):
+    """Raw batched GEMM on pointers with element offsets: sa/sb/sc = (outer stride, inner stride)."""
+    _lib.call("ppf_gemm_bf16_batched", a, b, c, M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), int(out_f32), float(alpha), bo, bi,
+              sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(kpad))
+
+
+class _Off:
+    """A device pointer at an element offset into a tensor (for sub-matrix views handed to the C ABI)."""
+
+    def __init__(self, t, off):
+        self.t, self.off = t, off
+
+    def data_ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+
+def th_scores(qkv, wl, bl, B, H, N, D):
+    NP = (N + 3) // 4 * 4
+    sp = torch.empty((B, H, N, NP), dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_th_scores", qkv, wl, bl, sp, B, H, N, D, NP)
+    return sp
+
+
+def th_softmax_mix(sp, ww, bw, hm_out):
+    B, H, N, NP = sp.shape
+    NPK = (N + 7) // 8 * 8
+    a16 = torch.empty((B, H, N, NPK), dtype=torch.bfloat16, device=sp.device)
+    _lib.call("ppf_th_softmax_mix", sp, a16, hm_out, ww, bw, B, H, N, NP, NPK)
+    return a16
+
+
+def th_softmax_bwd(prob, da, ww, wl, dww, dbw, dbl):
+    B, H, N, NP = prob.shape
+    NPK = (N + 7) // 8 * 8
+    ds16 = torch.empty((B, H, N, NPK), dtype=torch.bfloat16, device=prob.device)
+    _lib.call("ppf_th_softmax_bwd", prob, da, ds16, ww, wl, dww, dbw, dbl, B, H, N, NP, NPK)
+    return ds16
+
+
+def th_dwl(qkv, ds_prime, dwl, B, H, N, D):
+    _lib.call("ppf_th_dwl", qkv, ds_prime, dwl, B, H, N, D, ds_prime.shape[-1])
+
+
+def class_attn_fwd(q, k, v, policy, B, H, N1, D):
+    dev = q.device
+    attn = torch.empty((B, H, N1), dtype=torch.float32, device=dev)
+    zinv = torch.empty((B, H), dtype=torch.float32, device=dev)
+    rowmean = torch.empty((B, N1), dtype=torch.float32, device=dev)
+    out = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+    _lib.call("ppf_class_attn_fwd", q, k, v, policy, attn, zinv, rowmean, out, B, H, N1, D)
+    return out, attn, zinv, rowmean
+
+
+def class_attn_bwd(q, k, v, attn, zinv, dout, B, H, N1, D):
+    dq = torch.empty_like(q)
+    dk = torch.empty_like(k)
+    dv = torch.empty_like(v)
+    _lib.call("ppf_class_attn_bwd", q, k, v, attn, zinv, dout, dq, dk, dv, B, H, N1, D)
+    return dq, dk, dv
+
+
+def merge3_cast(a, b, cq, N1):
+    rows, D = a.shape
+    out = torch.empty((rows, D), dtype=torch.bfloat16, device=a.device)
+    _lib.call("ppf_merge3_cast", a, b, cq, out, rows, D, N1)
+    return out
