@@ -129,7 +129,7 @@ int ppf_cross_entropy(const float* logits, const void* label_i64, float* per_sam
                       ppf_stream_t stream);
 /* last_layer / last_layer_global (protopformer.py:126-131, 314-316): C = alpha * A B^T + beta * C, arbitrary strides */
 int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk,
-              int ldc, float alpha, float beta, ppf_stream_t stream);
+              int ldc, float alpha, float beta, float* workspace, int64_t workspace_floats, ppf_stream_t stream);
 int ppf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, ppf_stream_t stream);
 
 /* ---- streaming kernels -------------------------------------------------------------------------------------------- */

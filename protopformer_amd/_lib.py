@@ -29,7 +29,7 @@ SIGS = {
     "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
     "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",
     "ppf_cross_entropy": "ppppp" "ii" "s",
-    "ppf_sgemm": "ppp" "iii" "llll" "i" "ff" "s",
+    "ppf_sgemm": "ppp" "iii" "llll" "i" "ff" "pl" "s",
     "ppf_axpby": "ppp" "ff" "l" "s",
     "ppf_topk_sorted": "piiips",
     "ppf_gemm_bf16_batched": "ppp" "iiiiii" "iii" "f" "ii" "llllll" "i" "s",

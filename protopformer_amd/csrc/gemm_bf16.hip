@@ -47,51 +47,58 @@ struct GemmParams {
     // batched problems (blockIdx.y = outer*batch_inner + inner): element offsets added to A / B / C
     int batch_inner;
     long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
+    int zslice;              // (device side) this workgroup's K slice
+    int nsplit;              // split-K slices; grid.x = tiles * nsplit, slice-major so that an XCD owns whole K slices
     int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
 };
 
 __device__ __forceinline__ int lds_off_mode0(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }
+// transposed tile [64 kc][ROWS r]: row pitch ROWS*2 bytes, 64-byte units XOR-swizzled by kc&3 inside each 256-byte group
+template <int ROWS>
 __device__ __forceinline__ int lds_off_mode1(int kc, int col) {
-    return kc * 256 + ((((col >> 5) ^ (kc & 3))) << 6) + ((col & 31) << 1);
+    return kc * (ROWS * 2) + ((((col >> 5) ^ (kc & 3))) << 6) + ((col & 31) << 1);
 }
 
-template <bool T>
+// Operand tile of ROWS rows (m or n) x 64 contraction values, staged global -> registers -> LDS by 256 threads.
+template <bool T, int ROWS>
 struct TileIO {
-    // Issue the 4 x 16-byte global loads of this thread for the tile at (row0, k0).
-    static __device__ __forceinline__ void gload(uint4 (&reg)[4], const bf16_t* __restrict__ X, int ld, int R, int row0,
-                                                 int k0, int kend, int tid, int kpad = 0) {
+    static constexpr int NLD = ROWS / 32;            // 16-byte loads per thread
+    static __device__ __forceinline__ void gload(uint4 (&reg)[NLD], const bf16_t* __restrict__ X, int ld, int R, int row0,
+                                                 int k0, int kend, int tid, int kpad) {
         if constexpr (!T) {
             const int c16 = tid & 7, rb = tid >> 3;
             const bool kok = kpad ? (k0 + c16 * 8) < kend : (k0 + c16 * 8 + 8) <= kend;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NLD; ++i) {
                 const int r = row0 + rb + 32 * i;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (kok && r < R) v = *reinterpret_cast<const uint4*>(X + (size_t)r * ld + k0 + c16 * 8);
                 reg[i] = v;
             }
         } else {
-            const int c16 = tid & 15, kb = tid >> 4;
+            constexpr int CPR = ROWS / 8;            // 16-byte chunks per kc row
+            const int c16 = tid % CPR, kb = tid / CPR;
             const int col = row0 + c16 * 8;
             const bool cok = kpad ? col < R : (col + 8) <= R;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kc = k0 + kb + 16 * i;
+            for (int i = 0; i < NLD; ++i) {
+                const int kc = k0 + kb + (256 / CPR) * i;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (cok && kc < kend) v = *reinterpret_cast<const uint4*>(X + (size_t)kc * ld + col);
                 reg[i] = v;
             }
         }
     }
-    static __device__ __forceinline__ void sstore(const uint4 (&reg)[4], unsigned char* tile, int tid) {
+    static __device__ __forceinline__ void sstore(const uint4 (&reg)[NLD], unsigned char* tile, int tid) {
         if constexpr (!T) {
             const int c16 = tid & 7, rb = tid >> 3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = reg[i];
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = reg[i];
         } else {
-            const int c16 = tid & 15, kb = tid >> 4;
+            constexpr int CPR = ROWS / 8;
+            const int c16 = tid % CPR, kb = tid / CPR;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode1(kb + 16 * i, c16 * 8)) = reg[i];
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode1<ROWS>(kb + (256 / CPR) * i, c16 * 8)) = reg[i];
         }
     }
     // Fragment of the 32-row sub-tile starting at rbase for k-substep ks (16 contraction values):
@@ -104,8 +111,8 @@ struct TileIO {
             const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
             const int col = rbase + 16 * g16 + 4 * (s & 3);
             const int kc = ks * 16 + 8 * h + (s >> 2);
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + lds_off_mode1(kc, col)));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + lds_off_mode1(kc + 4, col)));
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + lds_off_mode1<ROWS>(kc, col)));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + lds_off_mode1<ROWS>(kc + 4, col)));
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
@@ -122,7 +129,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
     }
     if constexpr (EPI == EPI_PARTIAL) {
         const size_t slice = (size_t)p.M * p.N + (p.colsum ? p.M : 0);
-        *reinterpret_cast<float4*>(p.ws + blockIdx.z * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p.ws + p.zslice * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
         return;
     }
     if (p.bias) {
@@ -166,16 +173,27 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
     }
 }
 
-template <bool TA, bool TB, int EPI, bool COLSUM, bool DBUF>
-__global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const GemmParams p_) {
+// MT = 32-row MFMA tiles per wave along m: MT = 2 -> 128x128 workgroup tile (3 workgroups/CU), MT = 4 -> 256x128 (wave tile
+// 128x64, 2 workgroups/CU): fewer LDS bytes and barriers per flop for the tall activation GEMMs (M = B*N tokens).
+template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
+__global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const GemmParams p_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TBM = 64 * MT;                    // workgroup tile rows
+    constexpr int A_BYTES = TBM * BK * 2;
+    using IOA = TileIO<TA, TBM>;
+    using IOB = TileIO<TB, BN>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int wm = (wave & 1) * (32 * MT), wn = (wave >> 1) * 64;
 
+    // 1-D grid over (K slice, m tile, n tile), n fastest, remapped so that each XCD gets a contiguous range: the n-tiles of an
+    // m-panel -- and, for split-K, all tiles of a K slice -- share one XCD's L2.
     const int tiles_n = (p_.N + BN - 1) / BN;
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (vid / tiles_n) * BM, n0 = (vid % tiles_n) * BN;
+    const int tiles = tiles_n * ((p_.M + TBM - 1) / TBM);
+    const int vid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int zslice = vid_all / tiles, vid = vid_all - zslice * tiles;
+    const int m0 = (vid / tiles_n) * TBM, n0 = (vid % tiles_n) * BN;
     GemmParams p = p_;
+    p.zslice = zslice;
     if (gridDim.y > 1) {
         const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y % p.batch_inner;
         p.A += bo * p.sa_o + bi * p.sa_i;
@@ -184,58 +202,57 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
         p.C = (EPI == EPI_BF16) ? (void*)(reinterpret_cast<bf16_t*>(p.C) + co) : (void*)(reinterpret_cast<float*>(p.C) + co);
     }
 
-    // contraction range of this z-slice (split-K): multiples of BK except the tail
-    const int nsplit = gridDim.z;
+    // contraction range of this K slice: multiples of BK except the tail
+    const int nsplit = p.nsplit;
     const int kchunk = (((p.K + nsplit - 1) / nsplit) + BK - 1) / BK * BK;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = zslice * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    uint4 ra[4], rb[4];
-    f32x16 acc[2][2];
+    uint4 ra[IOA::NLD], rb[IOB::NLD];
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x16 accs[2];
+    f32x16 accs[MT];
     if constexpr (COLSUM) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accs[j][r] = 0.f;
     }
     const bool do_colsum = COLSUM && p.colsum != nullptr && n0 == 0 && wn == 0;
+    unsigned char* tA = smem;
+    unsigned char* tB = smem + A_BYTES;
 
-    TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid, p.kpad);
-    TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid, p.kpad);
-    TileIO<TA>::sstore(ra, smem, tid);
-    TileIO<TB>::sstore(rb, smem + TILE_BYTES, tid);
+    IOA::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid, p.kpad);
+    IOB::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid, p.kpad);
+    IOA::sstore(ra, tA, tid);
+    IOB::sstore(rb, tB, tid);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = DBUF ? (kt & 1) : 0;
-        const unsigned char* tA = smem + buf * 2 * TILE_BYTES;
-        const unsigned char* tB = tA + TILE_BYTES;
         const bool more = (kt + 1) < nk;
-        if (more) {
+        if (more) {                                          // next tile's loads fly while this tile is multiplied
             const int k0 = kbeg + (kt + 1) * BK;
-            TileIO<TA>::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
-            TileIO<TB>::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
+            IOA::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
+            IOB::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[MT], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = TileIO<TA>::frag(tA, wm + 32 * i, ks, lane);
+            for (int i = 0; i < MT; ++i) fa[i] = IOA::frag(tA, wm + 32 * i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fb[i] = TileIO<TB>::frag(tB, wn + 32 * i, ks, lane);
+            for (int i = 0; i < 2; ++i) fb[i] = IOB::frag(tB, wn + 32 * i, ks, lane);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
             if constexpr (COLSUM) {
                 if (do_colsum) {
@@ -243,16 +260,15 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MT; ++mi)
                         accs[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[mi], accs[mi], 0, 0, 0);
                 }
             }
         }
-        if constexpr (!DBUF) __syncthreads();               // single LDS buffer: everyone finished reading it
+        __syncthreads();                                     // single LDS operand buffer: everyone finished reading it
         if (more) {
-            unsigned char* nA = smem + (DBUF ? (buf ^ 1) : 0) * 2 * TILE_BYTES;
-            TileIO<TA>::sstore(ra, nA, tid);
-            TileIO<TB>::sstore(rb, nA + TILE_BYTES, tid);
+            IOA::sstore(ra, tA, tid);
+            IOB::sstore(rb, tB, tid);
         }
         __syncthreads();
     }
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
     const int h = lane >> 5;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * STAGE_LD);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -284,35 +300,43 @@ __global__ __launch_bounds__(NTHREADS, DBUF ? 2 : 3) void gemm_kernel(const Gemm
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
             if (do_colsum && h == 0 && m < p.M) {
-                if constexpr (EPI == EPI_PARTIAL) p.ws[blockIdx.z * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
+                if constexpr (EPI == EPI_PARTIAL) p.ws[p.zslice * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
                 else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
             }
         }
     }
 }
 
-template <bool TA, bool TB, int EPI, bool COLSUM, bool DBUF>
-int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, DBUF>;
-    constexpr int lds = ((DBUF ? 4 : 2) * TILE_BYTES) > STAGE_BYTES ? ((DBUF ? 4 : 2) * TILE_BYTES) : STAGE_BYTES;
+template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
+int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch) {
+    constexpr int TBM = 64 * MT;
+    const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + BN - 1) / BN);
+    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, MT>;
+    constexpr int opnd = TBM * BK * 2 + TILE_BYTES;
+    constexpr int lds = opnd > STAGE_BYTES ? opnd : STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, nbatch, splitk), dim3(NTHREADS), lds, stream, p);
+    GemmParams q = p;
+    q.nsplit = splitk;
+    hipLaunchKernelGGL(kern, dim3(tiles * splitk, nbatch, 1), dim3(NTHREADS), lds, stream, q);
     PPF_LAUNCH_CHECK();
     return 0;
 }
 
+// Tile choice: 256x128 when the m extent is tall enough to fill the chip with 256-row tiles (activation GEMMs), else 128x128.
+// PPF_GEMM_MT=2 / 4 forces one (A/B measurements in profiles/).
 template <bool TA, bool TB, int EPI, bool COLSUM>
 int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) {
-    // default: single LDS operand buffer (32 KiB) -> 3 workgroups/CU; PPF_GEMM_DBUF=1 selects the double-buffered variant
-    // (one barrier per K tile, 2 workgroups/CU), measured 8-15 % slower at this model's shapes (profiles/r1_gemm_ab.txt)
-    static const bool single = !(getenv("PPF_GEMM_DBUF") != nullptr && getenv("PPF_GEMM_DBUF")[0] == '1');
-    return single ? launch_impl<TA, TB, EPI, COLSUM, false>(p, splitk, stream, nbatch) : launch_impl<TA, TB, EPI, COLSUM, true>(p, splitk, stream, nbatch);
+    static const int forced = getenv("PPF_GEMM_MT") ? atoi(getenv("PPF_GEMM_MT")) : 0;
+    const long long tall_tiles = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * splitk * nbatch;
+    // measured (profiles/r1_gemm_tile_ab.txt): the 256x128 tile is 5-30 % slower at every shape of this model -> opt-in only
+    (void)tall_tiles;
+    const bool tall = forced == 4;
+    return tall ? launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch) : launch_impl<TA, TB, EPI, COLSUM, 2>(p, splitk, stream, nbatch);
 }
 
 // out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the M partial column sums

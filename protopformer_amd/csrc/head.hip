@@ -139,18 +139,26 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* logits, const long
     for (int c = lane; c < C; c += 64) dlogits[(size_t)b * C + c] = (__expf(row[c] - lse) - (c == lab ? 1.0f : 0.0f)) * invB;
 }
 
-// C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m][n]; 32x32 tile, 2x2 per thread
-__global__ __launch_bounds__(256) void sgemm_kernel(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak,
-                                                    int64_t sbn, int64_t sbk, int ldc, float alpha, float beta) {
+// C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m][n]; 32x32 tile, 2x2 outputs per thread.
+// The problems here are tiny but deep (256 x 200 x 2000): the contraction is split over gridDim.z slices that write partial
+// tiles, reduced in fixed order by sgemm_reduce_kernel (deterministic), so that >400 workgroups share the latency-bound K loop.
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                    float* __restrict__ part, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn,
+                                                    int64_t sbk, int ldc, float alpha, float beta) {
     __shared__ float sa[32][33], sb[32][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kchunk = ((K + gridDim.z - 1) / gridDim.z + 31) / 32 * 32;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
         for (int i = threadIdx.x; i < 1024; i += 256) {
-            const int r = i >> 5, k = i & 31;
-            sa[r][k] = (m0 + r < M && k0 + k < K) ? A[(size_t)(m0 + r) * sam + (size_t)(k0 + k) * sak] : 0.f;
-            sb[r][k] = (n0 + r < N && k0 + k < K) ? Bm[(size_t)(n0 + r) * sbn + (size_t)(k0 + k) * sbk] : 0.f;
+            int r, k;
+            if (a_kfast) { k = i & 31; r = i >> 5; } else { r = i & 31; k = i >> 5; }
+            sa[r][k] = (m0 + r < M && k0 + k < kend) ? A[(size_t)(m0 + r) * sam + (size_t)(k0 + k) * sak] : 0.f;
+            if (b_kfast) { k = i & 31; r = i >> 5; } else { r = i & 31; k = i >> 5; }
+            sb[r][k] = (n0 + r < N && k0 + k < kend) ? Bm[(size_t)(n0 + r) * sbn + (size_t)(k0 + k) * sbk] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -166,10 +174,20 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* A, const float*
         for (int j = 0; j < 2; ++j) {
             const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
             if (m < M && n < N) {
-                float* c = C + (size_t)m * ldc + n;
-                *c = alpha * acc[i][j] + (beta != 0.f ? beta * *c : 0.f);
+                if (gridDim.z > 1) part[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j];
+                else { float* c = C + (size_t)m * ldc + n; *c = alpha * acc[i][j] + (beta != 0.f ? beta * *c : 0.f); }
             }
         }
+}
+
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, int ldc, int S,
+                                                           float alpha, float beta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += part[(size_t)z * M * N + i];
+    float* c = C + (size_t)(i / N) * ldc + (i % N);
+    *c = alpha * s + (beta != 0.f ? beta * *c : 0.f);
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, float a, float b, int64_t n) {
@@ -215,11 +233,23 @@ int ppf_cross_entropy(const float* logits, const void* label, float* per_sample,
 }
 
 // Small strided fp32 GEMM for the frozen class-connection layers: C = alpha * A B^T + beta * C.
+// workspace (optional): fp32 scratch of ksplit*M*N floats enabling the split contraction (ksplit = workspace_floats / (M*N), <= 16).
 int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int ldc,
-              float alpha, float beta, hipStream_t stream) {
+              float alpha, float beta, float* workspace, int64_t workspace_floats, hipStream_t stream) {
     PPF_CHECK_ARG(M > 0 && N > 0 && K > 0, PPF_ERR_SHAPE, "ppf_sgemm: bad shape");
-    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, stream, A, Bm, C, M, N, K, sam, sak, sbn, sbk, ldc, alpha, beta);
+    int S = workspace ? (int)(workspace_floats / ((int64_t)M * N)) : 1;
+    if (S > 16) S = 16;
+    if (S > (K + 127) / 128) S = (K + 127) / 128;
+    if (S < 1) S = 1;
+    const int kchunk = ((K + S - 1) / S + 31) / 32 * 32;
+    S = (K + kchunk - 1) / kchunk;                          // no empty slices
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, S), dim3(256), 0, stream, A, Bm, C, workspace, M, N, K, sam, sak, sbn, sbk,
+                       ldc, alpha, beta);
     PPF_LAUNCH_CHECK();
+    if (S > 1) {
+        hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, workspace, C, M, N, ldc, S, alpha, beta);
+        PPF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

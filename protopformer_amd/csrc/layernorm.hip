@@ -158,6 +158,138 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
     if (p.cast_out) { flush(anb, p.dbias_next); if (p.branch) flush(acs, p.dcolscale); }
 }
 
+// Bandwidth-oriented variant for D = 32*V*NJ (V = 4: D % 128 == 0, V = 2: D % 64 == 0): half a wavefront per row, so a
+// wave streams two independent rows at a time with 16-/8-byte accesses (twice the loads in flight of the generic kernel).
+template <int V, int NJ>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
+    __shared__ float red[WAVES][NJ * V * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+    const int D = p.D;
+    float wv[NJ][V], cs[NJ][V], adw[NJ][V], adb[NJ][V], anb[NJ][V], acs[NJ][V];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = V * l32 + 32 * V * j + e;
+            wv[j][e] = p.dy ? p.w[c] : 0.f;
+            cs[j][e] = p.colscale ? p.colscale[c] : 1.f;
+            adw[j][e] = adb[j][e] = anb[j][e] = acs[j][e] = 0.f;
+        }
+    const float invD = 1.0f / (float)D;
+    for (int r0 = (blockIdx.x * WAVES + wave) * 2; r0 < p.rows; r0 += gridDim.x * WAVES * 2) {
+        const int r = r0 + half;
+        const bool ok = r < p.rows;
+        const size_t src = ok ? (p.row_map ? (size_t)p.row_map[r] : (size_t)r) : 0;
+        float dx[NJ][V];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = V * l32 + 32 * V * j;
+            if (p.dres_in && ok) {
+                if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p.dres_in + src * D + c); dx[j][0] = t.x; dx[j][1] = t.y; dx[j][2] = t.z; dx[j][3] = t.w; }
+                else { const float2 t = *reinterpret_cast<const float2*>(p.dres_in + src * D + c); dx[j][0] = t.x; dx[j][1] = t.y; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) dx[j][e] = 0.f;
+            }
+        }
+        if (p.dy) {
+            const float mu = ok ? p.mean[r] : 0.f, rs = ok ? p.rstd[r] : 0.f;
+            float xh[NJ][V], g[NJ][V];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = V * l32 + 32 * V * j;
+                float xv[V], dyv[V];
+                if (ok) {
+                    if constexpr (V == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.x + src * D + c); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                        const uint2 u = *reinterpret_cast<const uint2*>(p.dy + (size_t)r * D + c);
+                        const float2 a = unpack_bf16x2(u.x), b = unpack_bf16x2(u.y); dyv[0] = a.x; dyv[1] = a.y; dyv[2] = b.x; dyv[3] = b.y;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(p.x + src * D + c); xv[0] = t.x; xv[1] = t.y;
+                        const float2 a = unpack_bf16x2(*reinterpret_cast<const uint32_t*>(p.dy + (size_t)r * D + c)); dyv[0] = a.x; dyv[1] = a.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) { xv[e] = 0.f; dyv[e] = 0.f; }
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    xh[j][e] = (xv[e] - mu) * rs;
+                    g[j][e] = dyv[e] * wv[j][e];
+                    s1 += g[j][e];
+                    s2 += g[j][e] * xh[j][e];
+                    adw[j][e] += dyv[e] * xh[j][e];
+                    adb[j][e] += dyv[e];
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            const float c1 = s1 * invD, c2 = s2 * invD;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) dx[j][e] += rs * (g[j][e] - c1 - xh[j][e] * c2);
+        }
+        if (!ok) continue;
+        const float rsc = p.rowscale ? p.rowscale[src / p.rows_per_group] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = V * l32 + 32 * V * j;
+            if (p.dx_out) {
+                if constexpr (V == 4) *reinterpret_cast<float4*>(p.dx_out + src * D + c) = make_float4(dx[j][0], dx[j][1], dx[j][2], dx[j][3]);
+                else *reinterpret_cast<float2*>(p.dx_out + src * D + c) = make_float2(dx[j][0], dx[j][1]);
+            }
+            if (p.cast_out) {
+                float sx[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) sx[e] = dx[j][e] * rsc;
+                if (p.branch) {
+                    float br[V];
+                    if constexpr (V == 4) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(p.branch + src * D + c);
+                        const float2 a = unpack_bf16x2(u.x), b = unpack_bf16x2(u.y); br[0] = a.x; br[1] = a.y; br[2] = b.x; br[3] = b.y;
+                    } else {
+                        const float2 a = unpack_bf16x2(*reinterpret_cast<const uint32_t*>(p.branch + src * D + c)); br[0] = a.x; br[1] = a.y;
+                    }
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acs[j][e] += sx[e] * br[e];
+                }
+                uint32_t pk[V / 2];
+#pragma unroll
+                for (int e = 0; e < V; e += 2) {
+                    pk[e / 2] = pack_bf16x2(sx[e] * cs[j][e], sx[e + 1] * cs[j][e + 1]);
+                    const float2 rt = unpack_bf16x2(pk[e / 2]);
+                    anb[j][e] += rt.x; anb[j][e + 1] += rt.y;
+                }
+                if constexpr (V == 4) *reinterpret_cast<uint2*>(p.cast_out + src * D + c) = make_uint2(pk[0], pk[1]);
+                else *reinterpret_cast<uint32_t*>(p.cast_out + src * D + c) = pk[0];
+            }
+        }
+    }
+    auto flush = [&](float (&a)[NJ][V], float* dst) {
+        if (!dst) return;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float v = a[j][e] + __shfl_xor(a[j][e], 32, 64);       // the two rows a wave works on
+                if (half == 0) red[wave][(j * 32 + l32) * V + e] = v;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NJ * V * 32; i += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < WAVES; ++w_) s += red[w_][i];
+            const int j = i / (32 * V), rem = i % (32 * V);
+            unsafeAtomicAdd(dst + 32 * V * j + rem, s);                      // column = V*l32 + e + 32*V*j
+        }
+    };
+    if (p.dy) { flush(adw, p.dw); flush(adb, p.db); }
+    if (p.cast_out) { flush(anb, p.dbias_next); if (p.branch) flush(acs, p.dcolscale); }
+}
+
 template <typename F>
 int dispatch_nj(int D, F&& f) {
     const int nj = (D + 127) / 128;
@@ -200,6 +332,10 @@ int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const 
     p.dw = dw; p.db = db; p.cast_out = (bf16_t*)cast_out; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.dbias_next = dbias_next; p.branch = (const bf16_t*)branch; p.dcolscale = dcolscale; p.rows = rows; p.D = D;
     const int grid = min((rows + WAVES * 8 - 1) / (WAVES * 8), 2048);      // >= 8 rows per wave: amortise the column atomics
+#define PPF_LN2(V, NJ) { hipLaunchKernelGGL((ln_bwd2_kernel<V, NJ>), dim3(grid), dim3(256), 0, stream, p); PPF_LAUNCH_CHECK(); return 0; }
+    if (D % 128 == 0 && D <= 512) { switch (D / 128) { case 1: PPF_LN2(4, 1) case 2: PPF_LN2(4, 2) case 3: PPF_LN2(4, 3) case 4: PPF_LN2(4, 4) } }
+    if (D % 64 == 0 && D <= 512) { switch (D / 64) { case 1: PPF_LN2(2, 1) case 3: PPF_LN2(2, 3) case 5: PPF_LN2(2, 5) case 7: PPF_LN2(2, 7) } }
+#undef PPF_LN2
     return dispatch_nj(D, [&](auto nj) {
         hipLaunchKernelGGL((ln_bwd_kernel<decltype(nj)::value>), dim3(grid), dim3(256), 0, stream, p);
         PPF_LAUNCH_CHECK();

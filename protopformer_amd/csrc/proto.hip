@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void proto_fwd_kernel(const ProtoFwdParams p) 
             }
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll
         for (int kk = 0; kk < BKF / 2; ++kk) {
             const float bv = lpro[(wave * 32 + (lane & 31)) * LDP + kk * 2 + hh];
             p2p += bv * bv;
@@ -306,20 +306,33 @@ __global__ __launch_bounds__(256) void proto_bwd_protos_kernel(const ProtoBwdPar
     float pv[NJ], acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; pv[j] = d < p.Dp ? prow[d] : 0.f; acc[j] = 0.f; }
-    for (int b = wave; b < p.B; b += NW) {
-        const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
-        const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
+    constexpr int UB = 4;                          // samples in flight per wave: their gradient rows are loaded together
+    for (int b0 = wave; b0 < p.B; b0 += NW * UB) {
         for (int tb = 0; tb < p.T; tb += 64) {
             const int t = tb + lane;
-            const float G = t < p.T ? grad_d(p, b, pi, t, am, gm) : 0.f;
-            unsigned long long m = __ballot(G != 0.f);
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const float g2 = 2.0f * __shfl(G, src, 64);
-                const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + tb + src) * p.Dp;
+            float G[UB];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (pv[j] - xrow[d]); }
+            for (int u = 0; u < UB; ++u) {
+                const int b = b0 + u * NW;
+                G[u] = 0.f;
+                if (b < p.B && t < p.T) {
+                    const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
+                    const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
+                    G[u] = grad_d(p, b, pi, t, am, gm);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int b = b0 + u * NW;
+                unsigned long long m = __ballot(G[u] != 0.f);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float g2 = 2.0f * __shfl(G[u], src, 64);
+                    const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + tb + src) * p.Dp;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (pv[j] - xrow[d]); }
+                }
             }
         }
     }

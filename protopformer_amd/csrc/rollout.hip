@@ -16,6 +16,8 @@ namespace {
 constexpr int NTHR = 1024, NWAVE = 16;
 constexpr int RPW = 14;      // rows per wave  (N <= 224)
 constexpr int CPL = 4;       // columns per lane (N <= 256)
+constexpr int HCOPIES = 16;  // histogram replicas
+constexpr int HSTRIDE = 257; // replica pitch (odd: replicas of one bin fall on different LDS banks)
 
 struct RolloutParams {
     const float* hm;         // [L][B][N][NP]
@@ -47,13 +49,15 @@ __device__ uint32_t radix_select(const float (&v)[NV], int target, uint32_t* his
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < HCOPIES * HSTRIDE; i += blockDim.x) hist[i] = 0;
         __syncthreads();
+        const int hcopy = (threadIdx.x & (HCOPIES - 1)) * HSTRIDE;     // attention values cluster in 2-3 exponent bins: spread the
+                                                                    // LDS atomics over HCOPIES histogram replicas
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const uint32_t key = order_key(v[i]);
             const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
-            if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            if (match) atomicAdd(&hist[hcopy + ((key >> shift) & 255u)], 1u);
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // bound the live key/bin temporaries
         }
         __syncthreads();
@@ -61,7 +65,10 @@ __device__ uint32_t radix_select(const float (&v)[NV], int target, uint32_t* his
         uint32_t cum = 0;
         if (threadIdx.x < 256) {
             const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-            uint32_t v = hist[threadIdx.x];
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < HCOPIES; ++c) v += hist[c * HSTRIDE + threadIdx.x];
+            hist[threadIdx.x] = v;                                  // replica 0 now holds the merged bin (own slot only)
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t n = __shfl_up(v, o, 64);
@@ -88,7 +95,7 @@ __device__ uint32_t radix_select(const float (&v)[NV], int target, uint32_t* his
 }
 
 __global__ __launch_bounds__(NTHR) void rollout_kernel(const RolloutParams p) {
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[HCOPIES * HSTRIDE];
     __shared__ uint32_t misc[16];
     __shared__ float r[256];               // current row vector
     __shared__ float rnew[NWAVE][256];     // per-wave partial column sums

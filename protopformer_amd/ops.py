@@ -210,7 +210,8 @@ def cross_entropy(logits, label):
 
 
 def sgemm(a, b, out, M, N, K, sam, sak, sbn, sbk, alpha=1.0, beta=0.0):
-    _lib.call("ppf_sgemm", a, b, out, M, N, K, sam, sak, sbn, sbk, out.shape[-1], float(alpha), float(beta))
+    ws = _workspace(out.device, 16 * M * N * 4)
+    _lib.call("ppf_sgemm", a, b, out, M, N, K, sam, sak, sbn, sbk, out.shape[-1], float(alpha), float(beta), ws, ws.numel() // 4)
     return out
 
 
