@@ -294,10 +294,11 @@ __global__ __launch_bounds__(512) void proto_bwd_tokens_kernel(const ProtoBwdPar
     }
 }
 
-// One workgroup (4 waves) per prototype; wave w owns samples w, w+4, ...; per sample it scans the T tokens.
+// One 16-wave workgroup per prototype; wave w owns samples w, w+16, ... (a short dependent-load chain per wave: the kernel is
+// latency-bound); per sample it scans the T tokens.  Partial rows are reduced through LDS in fixed order.
 template <int NJ>
-__global__ __launch_bounds__(256) void proto_bwd_protos_kernel(const ProtoBwdParams p) {
-    constexpr int NW = 4;
+__global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdParams p) {
+    constexpr int NW = 16;
     __shared__ float red[NW][NJ * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -306,40 +307,27 @@ __global__ __launch_bounds__(256) void proto_bwd_protos_kernel(const ProtoBwdPar
     float pv[NJ], acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; pv[j] = d < p.Dp ? prow[d] : 0.f; acc[j] = 0.f; }
-    constexpr int UB = 4;                          // samples in flight per wave: their gradient rows are loaded together
-    for (int b0 = wave; b0 < p.B; b0 += NW * UB) {
+    for (int b = wave; b < p.B; b += NW) {
+        const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
+        const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
         for (int tb = 0; tb < p.T; tb += 64) {
             const int t = tb + lane;
-            float G[UB];
+            const float G = t < p.T ? grad_d(p, b, pi, t, am, gm) : 0.f;
+            unsigned long long m = __ballot(G != 0.f);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const float g2 = 2.0f * __shfl(G, src, 64);
+                const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + tb + src) * p.Dp;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int b = b0 + u * NW;
-                G[u] = 0.f;
-                if (b < p.B && t < p.T) {
-                    const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
-                    const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
-                    G[u] = grad_d(p, b, pi, t, am, gm);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int b = b0 + u * NW;
-                unsigned long long m = __ballot(G[u] != 0.f);
-                while (m) {
-                    const int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float g2 = 2.0f * __shfl(G[u], src, 64);
-                    const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + tb + src) * p.Dp;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (pv[j] - xrow[d]); }
-                }
+                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (pv[j] - xrow[d]); }
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) red[wave][j * 64 + lane] = acc[j];
     __syncthreads();
-    for (int i = threadIdx.x; i < NJ * 64; i += 256) {
+    for (int i = threadIdx.x; i < NJ * 64; i += 1024) {
         const int d = (i & 63) + 64 * (i >> 6);
         if (d < p.Dp) {
             float s = 0.f;
@@ -403,7 +391,7 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
             hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(grid), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
             hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
         }
-        if (dprotos) hipLaunchKernelGGL((proto_bwd_protos_kernel<NJ>), dim3(P), dim3(256), 0, stream, p);
+        if (dprotos) hipLaunchKernelGGL((proto_bwd_protos_kernel<NJ>), dim3(P), dim3(1024), 0, stream, p);
     };
     if (nj <= 1) run(std::integral_constant<int, 1>());
     else if (nj <= 2) run(std::integral_constant<int, 2>());
