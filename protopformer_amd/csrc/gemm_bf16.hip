@@ -18,39 +18,17 @@
 // output row m: 8/16-byte row-major stores and vector bias/residual accesses.
 // blockIdx is remapped XCD-aware (n-tiles of one m-panel share an XCD's L2).
 #include "ppf_common.h"
+#include "gemm_common.h"
 #include <cstdlib>
 
 namespace {
+using namespace ppfg;
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile (either mode)
 constexpr int STAGE_LD = 68;                     // fp32 pitch of the per-wave epilogue strip (64 + 4: conflict-free float4 rows)
 constexpr int STAGE_BYTES = 4 * 32 * STAGE_LD * 4;   // 4 waves x 32 rows
 
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_SIGMOID_F32 = 3, EPI_RESID = 4, EPI_DGELU = 5, EPI_ATOMIC = 6, EPI_PARTIAL = 7 };
-
-struct GemmParams {
-    const bf16_t* A; const bf16_t* B; void* C;
-    int M, N, K, lda, ldb, ldc;
-    const float* bias;       // [N] (added before activation) or null
-    const float* res;        // EPI_RESID: fp32 residual [M][ldres]
-    int ldres;
-    const float* rowscale;   // EPI_RESID: per-sample scale, index m / rows_per_group (DropPath), or null
-    int rows_per_group;
-    const float* colscale;   // EPI_RESID: per-column scale (LayerScale gamma), or null
-    const bf16_t* aux_in;    // EPI_DGELU: pre-activation h [M][ldaux]
-    bf16_t* aux_out;         // EPI_GELU: pre-activation out; EPI_RESID: raw branch output (optional)
-    int ldaux;
-    float* colsum;           // EPI_ATOMIC + TA: sum over kc of A(m,kc) accumulated atomically into colsum[m]
-    float* ws;               // EPI_PARTIAL: split-K workspace [nsplit][M*N (+M)] fp32 partial tiles (+ partial column sums)
-    float alpha;
-    // batched problems (blockIdx.y = outer*batch_inner + inner): element offsets added to A / B / C
-    int batch_inner;
-    long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
-    int zslice;              // (device side) this workgroup's K slice
-    int nsplit;              // split-K slices; grid.x = tiles * nsplit, slice-major so that an XCD owns whole K slices
-    int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
-};
 
 __device__ __forceinline__ int lds_off_mode0(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }
 // transposed tile [64 kc][ROWS r]: row pitch ROWS*2 bytes, 64-byte units XOR-swizzled by kc&3 inside each 256-byte group
@@ -118,60 +96,6 @@ struct TileIO {
     }
 };
 
-template <int EPI>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, float v0, float v1, float v2, float v3) {
-    float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
-    if constexpr (EPI == EPI_ATOMIC) {
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(c + i, v[i]);
-        return;
-    }
-    if constexpr (EPI == EPI_PARTIAL) {
-        const size_t slice = (size_t)p.M * p.N + (p.colsum ? p.M : 0);
-        *reinterpret_cast<float4*>(p.ws + p.zslice * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
-        return;
-    }
-    if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    if constexpr (EPI == EPI_BF16) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
-            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-    } else if constexpr (EPI == EPI_F32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == EPI_GELU) {
-        *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
-            make_uint2(pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3])));
-    } else if constexpr (EPI == EPI_SIGMOID_F32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + __expf(-v[i]));
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == EPI_RESID) {
-        if (p.aux_out)
-            *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        if (p.colscale) {
-            const float4 g = *reinterpret_cast<const float4*>(p.colscale + n0);
-            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
-        }
-        if (p.rowscale) {
-            const float s = p.rowscale[m / p.rows_per_group];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= s;
-        }
-        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n0);
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) =
-            make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
-    } else if constexpr (EPI == EPI_DGELU) {
-        const uint2 h = *reinterpret_cast<const uint2*>(p.aux_in + (size_t)m * p.ldaux + n0);
-        const float2 h01 = unpack_bf16x2(h.x), h23 = unpack_bf16x2(h.y);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
-            make_uint2(pack_bf16x2(v[0] * gelu_erf_grad(h01.x), v[1] * gelu_erf_grad(h01.y)),
-                       pack_bf16x2(v[2] * gelu_erf_grad(h23.x), v[3] * gelu_erf_grad(h23.y)));
-    }
-}
 
 // MT = 32-row MFMA tiles per wave along m: MT = 2 -> 128x128 workgroup tile (3 workgroups/CU), MT = 4 -> 256x128 (wave tile
 // 128x64, 2 workgroups/CU): fewer LDS bytes and barriers per flop for the tall activation GEMMs (M = B*N tokens).
@@ -386,8 +310,8 @@ size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 // Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
-// epi: 0 bf16 out, 1 f32 out, 2 bias+GELU (C = gelu bf16, aux_out = pre-activation bf16), 3 sigmoid f32 out,
-//      4 residual (C f32 = res + rowscale*colscale*(acc+bias), optional aux_out raw bf16), 5 dGELU (C bf16 = acc*gelu'(aux_in)),
+// epi: 0 bf16 out, 1 f32 out, 2 bias+GELU (C = gelu(pre) bf16, aux_out = gelu'(pre) bf16), 3 sigmoid f32 out,
+//      4 residual (C f32 = res + rowscale*colscale*(acc+bias), optional aux_out raw bf16), 5 dGELU (C bf16 = acc*aux_in, aux_in = the gelu' written by epi 2),
 //      6 f32 accumulate into C (C += ...; split over the contraction; optional colsum[m] += sum_kc A(m,kc) when trans_a).
 //        With a workspace of ppf_gemm_workspace_bytes(M,N,K) the slices write partial tiles that a second kernel reduces in a
 //        fixed order (deterministic, no atomics); without one the slices fall back to fp32 atomics on C.
@@ -411,6 +335,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
     if (!trans_a && !trans_b) {
+        if (nt256_eligible(p, epi)) return launch_nt256(p, epi, stream);
         switch (epi) {
             case EPI_BF16: return launch<false, false, EPI_BF16, false>(p, 1, stream);
             case EPI_F32: return launch<false, false, EPI_F32, false>(p, 1, stream);

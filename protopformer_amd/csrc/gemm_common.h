@@ -1,0 +1,92 @@
+// Shared declarations of the bf16 MFMA GEMM family (gemm_bf16.hip: 128x128 generic kernel; gemm_nt256.hip: 256x256 pipelined kernel).
+#pragma once
+#include "ppf_common.h"
+
+namespace ppfg {
+
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_GELU = 2, EPI_SIGMOID_F32 = 3, EPI_RESID = 4, EPI_DGELU = 5, EPI_ATOMIC = 6, EPI_PARTIAL = 7 };
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias;       // [N] (added before activation) or null
+    const float* res;        // EPI_RESID: fp32 residual [M][ldres]
+    int ldres;
+    const float* rowscale;   // EPI_RESID: per-sample scale, index m / rows_per_group (DropPath), or null
+    int rows_per_group;
+    const float* colscale;   // EPI_RESID: per-column scale (LayerScale gamma), or null
+    const bf16_t* aux_in;    // EPI_DGELU: gelu'(pre-activation) [M][ldaux], as written by EPI_GELU
+    bf16_t* aux_out;         // EPI_GELU: gelu'(pre-activation) out; EPI_RESID: raw branch output (optional)
+    int ldaux;
+    float* colsum;           // EPI_ATOMIC + TA: sum over kc of A(m,kc) accumulated atomically into colsum[m]
+    float* ws;               // EPI_PARTIAL: split-K workspace [nsplit][M*N (+M)] fp32 partial tiles (+ partial column sums)
+    float alpha;
+    // batched problems (blockIdx.y = outer*batch_inner + inner): element offsets added to A / B / C
+    int batch_inner;
+    long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
+    int zslice;              // (device side) this workgroup's K slice
+    int nsplit;              // split-K slices; grid.x = tiles * nsplit, slice-major so that an XCD owns whole K slices
+    int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, float v0, float v1, float v2, float v3) {
+    float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
+    if constexpr (EPI == EPI_ATOMIC) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(c + i, v[i]);
+        return;
+    }
+    if constexpr (EPI == EPI_PARTIAL) {
+        const size_t slice = (size_t)p.M * p.N + (p.colsum ? p.M : 0);
+        *reinterpret_cast<float4*>(p.ws + p.zslice * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        return;
+    }
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if constexpr (EPI == EPI_BF16) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    } else if constexpr (EPI == EPI_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_GELU) {
+        float g[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gelu_erf_both(v[i], g[i], d[i]);
+        *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+    } else if constexpr (EPI == EPI_SIGMOID_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + __expf(-v[i]));
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_RESID) {
+        if (p.aux_out)
+            *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (p.colscale) {
+            const float4 g = *reinterpret_cast<const float4*>(p.colscale + n0);
+            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+        }
+        if (p.rowscale) {
+            const float s = p.rowscale[m / p.rows_per_group];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= s;
+        }
+        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n0);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
+    } else if constexpr (EPI == EPI_DGELU) {
+        const uint2 h = *reinterpret_cast<const uint2*>(p.aux_in + (size_t)m * p.ldaux + n0);
+        const float2 h01 = unpack_bf16x2(h.x), h23 = unpack_bf16x2(h.y);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
+            make_uint2(pack_bf16x2(v[0] * h01.x, v[1] * h01.y), pack_bf16x2(v[2] * h23.x, v[3] * h23.y));
+    }
+}
+
+// 256x256x64 pipelined kernel for contraction-contiguous operands (gemm_nt256.hip)
+bool nt256_eligible(const GemmParams& p, int epi);
+int launch_nt256(const GemmParams& p, int epi, hipStream_t stream);
+
+}  // namespace ppfg

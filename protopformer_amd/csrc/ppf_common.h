@@ -78,6 +78,13 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f, e));
     return cdf + x * 0.39894228040143267794f * e;
 }
+// gelu(x) and gelu'(x) from one erf / exp evaluation: the fc1 epilogue stores both, so the backward epilogue is a plain multiply
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& d) {
+    float e;
+    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f, e));
+    g = x * cdf;
+    d = cdf + x * 0.39894228040143267794f * e;
+}
 
 // Bijective XCD-aware remap of a 1-D block id: consecutive virtual ids land on the same XCD (private L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -294,12 +294,21 @@ __global__ __launch_bounds__(512) void proto_bwd_tokens_kernel(const ProtoBwdPar
     }
 }
 
-// One 16-wave workgroup per prototype; wave w owns samples w, w+16, ... (a short dependent-load chain per wave: the kernel is
-// latency-bound); per sample it scans the T tokens.  Partial rows are reduced through LDS in fixed order.
+// Prototype gradients: one 16-wave workgroup per prototype, two passes over blocks of 16 x 1024 (sample, token) elements.
+//  scan   : wave w streams its 1024 consecutive elements of dL/dd (coalesced, 8 independent 64-wide loads in flight) and
+//           compacts the non-zeros -- the arg-max token of every sample plus the dense rows of the samples whose label owns
+//           this prototype -- into an ascending per-wave LDS list (index, dL/dd).
+//  gather : the concatenated list is dealt out evenly to the 16 waves (the dense rows no longer sit on one wave); each wave
+//           fetches four token rows per step and accumulates 2 G (p - x) in exact fp32.
+// Partial rows are reduced through LDS in fixed order: deterministic, no float atomics.
+constexpr int PB_NW = 16, PB_CHUNK = 1024;
 template <int NJ>
 __global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdParams p) {
-    constexpr int NW = 16;
-    __shared__ float red[NW][NJ * 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
+    float* gl = reinterpret_cast<float*>(pb_smem);                                        // [NW][CHUNK] dL/dd
+    unsigned short* il = reinterpret_cast<unsigned short*>(gl + PB_NW * PB_CHUNK);       // [NW][CHUNK] element index inside the wave's range
+    float* red = reinterpret_cast<float*>(il + PB_NW * PB_CHUNK);                         // [NW][NJ*64]
+    int* cnt = reinterpret_cast<int*>(red + PB_NW * NJ * 64);                             // [NW + 1] exclusive prefix of the list lengths
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pi = blockIdx.x;
@@ -307,32 +316,96 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdPa
     float pv[NJ], acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; pv[j] = d < p.Dp ? prow[d] : 0.f; acc[j] = 0.f; }
-    for (int b = wave; b < p.B; b += NW) {
-        const int am = p.argmax ? p.argmax[(size_t)b * p.P + pi] : 0;
-        const float gm = p.g_max ? p.g_max[(size_t)b * p.P + pi] : 0.f;
-        for (int tb = 0; tb < p.T; tb += 64) {
-            const int t = tb + lane;
-            const float G = t < p.T ? grad_d(p, b, pi, t, am, gm) : 0.f;
-            unsigned long long m = __ballot(G != 0.f);
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const float g2 = 2.0f * __shfl(G, src, 64);
-                const float* xrow = p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + tb + src) * p.Dp;
+    const int E = p.B * p.T;
+    const float invT = 1.0f / (float)p.T;
+    const size_t PT = (size_t)p.P * p.T;
+    for (int blk0 = 0; blk0 < E; blk0 += PB_NW * PB_CHUNK) {
+        // ---- scan + compact
+        const int w0 = blk0 + wave * PB_CHUNK;
+        int n = 0;
+        for (int s0 = 0; s0 < PB_CHUNK; s0 += 8 * 64) {
+            float g[8]; int bb[8], tt[8];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) acc[j] += g2 * (pv[j] - xrow[d]); }
+            for (int u = 0; u < 8; ++u) {
+                const int e = w0 + s0 + u * 64 + lane;
+                int b = __float2int_rz(((float)e + 0.5f) * invT);
+                int t = e - b * p.T;
+                if (t < 0) { --b; t += p.T; } else if (t >= p.T) { ++b; t -= p.T; }
+                bb[u] = b; tt[u] = t;
+                g[u] = 0.f;
+                if (e < E) {
+                    const size_t bp = (size_t)b * p.P + pi;
+                    if (p.g_full) g[u] = p.g_full[bp * p.T + t];
+                    if (p.g_max) { const int am = p.argmax ? p.argmax[bp] : 0; if (t == am) g[u] += p.g_max[bp]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float G = 0.f;
+                if (g[u] != 0.f) G = g[u] * dact_dd(p.dist_full[(size_t)bb[u] * PT + (size_t)pi * p.T + tt[u]], p.act_kind, p.eps);
+                const unsigned long long m = __ballot(G != 0.f);
+                if (G != 0.f) {
+                    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                    gl[wave * PB_CHUNK + pos] = G;
+                    il[wave * PB_CHUNK + pos] = (unsigned short)(s0 + u * 64 + lane);
+                }
+                n += __popcll(m);
             }
         }
+        if (lane == 0) cnt[wave + 1] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) { int a = 0; cnt[0] = 0; for (int w = 1; w <= PB_NW; ++w) { a += cnt[w]; cnt[w] = a; } }
+        __syncthreads();
+        // ---- gather: entries [k0, k1) of the concatenated list
+        const int total = cnt[PB_NW];
+        const int k0 = (int)(((long long)total * wave) / PB_NW), k1 = (int)(((long long)total * (wave + 1)) / PB_NW);
+        for (int kb = k0; kb < k1; kb += 64) {
+            const int nn = min(64, k1 - kb);
+            float g2 = 0.f; long long roff = 0;
+            if (lane < nn) {
+                const int k = kb + lane;
+                int sw = 0;
+#pragma unroll
+                for (int w = 1; w < PB_NW; ++w) sw += (k >= cnt[w]) ? 1 : 0;
+                const int li = k - cnt[sw];
+                g2 = 2.0f * gl[sw * PB_CHUNK + li];
+                const int e = blk0 + sw * PB_CHUNK + il[sw * PB_CHUNK + li];
+                int b = __float2int_rz(((float)e + 0.5f) * invT);
+                int t = e - b * p.T;
+                if (t < 0) { --b; t += p.T; } else if (t >= p.T) { ++b; t -= p.T; }
+                roff = (long long)b * p.stride_b + (long long)(p.t0 + t) * p.Dp;
+            }
+            for (int e4 = 0; e4 < nn; e4 += 4) {
+                float gs[4]; const float* xr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int src = min(e4 + u, nn - 1);
+                    gs[u] = (e4 + u < nn) ? __shfl(g2, src, 64) : 0.f;
+                    const int lo = __shfl((int)(roff & 0xffffffffll), src, 64), hi = __shfl((int)(roff >> 32), src, 64);
+                    xr[u] = p.tok + (((long long)hi << 32) | (unsigned int)lo);
+                }
+                float v[4][NJ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; v[u][j] = d < p.Dp ? xr[u][d] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[j] += gs[u] * (pv[j] - v[u][j]);
+            }
+        }
+        __syncthreads();                                     // lists are rewritten by the next block
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) red[wave][j * 64 + lane] = acc[j];
+    for (int j = 0; j < NJ; ++j) red[wave * (NJ * 64) + j * 64 + lane] = acc[j];
     __syncthreads();
     for (int i = threadIdx.x; i < NJ * 64; i += 1024) {
         const int d = (i & 63) + 64 * (i >> 6);
         if (d < p.Dp) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += red[w][i];
+            for (int w = 0; w < PB_NW; ++w) s += red[w * (NJ * 64) + i];
             p.dprotos[(size_t)pi * p.Dp + d] += s;           // single writer per (prototype, d)
         }
     }
@@ -391,7 +464,15 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
             hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(grid), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
             hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
         }
-        if (dprotos) hipLaunchKernelGGL((proto_bwd_protos_kernel<NJ>), dim3(P), dim3(1024), 0, stream, p);
+        if (dprotos) {
+            constexpr int lds = PB_NW * PB_CHUNK * 6 + PB_NW * NJ * 64 * 4 + (PB_NW + 1) * 4;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proto_bwd_protos_kernel<NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((proto_bwd_protos_kernel<NJ>), dim3(P), dim3(1024), lds, stream, p);
+        }
     };
     if (nj <= 1) run(std::integral_constant<int, 1>());
     else if (nj <= 2) run(std::integral_constant<int, 2>());

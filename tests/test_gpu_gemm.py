@@ -48,7 +48,8 @@ def test_gemm_gelu_sigmoid_resid():
     pre = a.float() @ b.float().t() + bias
     h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     g = ops.gemm(a, b, epi=ops.EPI_GELU, bias=bias, aux_out=h)
-    assert_close(h.float(), pre.bfloat16().float(), rtol=8e-3, atol=1e-3, what="pre-activation")
+    gp = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    assert_close(h.float(), gp.bfloat16().float(), rtol=8e-3, atol=1e-3, what="gelu' saved for backward")
     assert_close(g.float(), torch.nn.functional.gelu(pre).bfloat16().float(), rtol=8e-3, atol=2e-3, what="gelu")
     s = ops.gemm(a, b, epi=ops.EPI_SIGMOID_F32, bias=bias)
     assert_close(s, torch.sigmoid(pre), rtol=1e-3, atol=1e-4, what="sigmoid")
@@ -71,11 +72,9 @@ def test_gemm_dgrad_nn(M, N, K):
     ref = dy.float() @ w.float()
     out = ops.gemm(dy, w, trans_b=True, epi=ops.EPI_F32)
     assert_close(out, ref, rtol=1e-3, atol=2e-3, what="dgrad")
-    hpre = _mk((M, N), 1.0, 3).bfloat16()
-    out2 = ops.gemm(dy, w, trans_b=True, epi=ops.EPI_DGELU, aux_in=hpre)
-    x = hpre.float()
-    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
-    assert_close(out2.float(), (ref * gp).bfloat16().float(), rtol=1e-2, atol=3e-3, what="dgelu")
+    gp = _mk((M, N), 0.5, 3).bfloat16()                      # gelu'(pre) as the EPI_GELU forward epilogue saves it
+    out2 = ops.gemm(dy, w, trans_b=True, epi=ops.EPI_DGELU, aux_in=gp)
+    assert_close(out2.float(), (ref * gp.float()).bfloat16().float(), rtol=1e-2, atol=3e-3, what="dgelu")
 
 
 @pytest.mark.parametrize("R,N,K", [(1000, 384, 384), (50432 // 8, 1152, 384), (777 * 8, 192, 768)])
@@ -92,3 +91,27 @@ def test_gemm_wgrad_tn_atomic(R, N, K):
     # accumulates (+=) into existing contents
     ops.gemm(dy, x, trans_a=True, trans_b=True, epi=ops.EPI_ATOMIC, out=dw)
     assert_close(dw, 2 * ref, rtol=1e-3, atol=2e-3 * scale, what="wgrad accumulate")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(24576, 512, 1024, "bf16"), (24600, 520, 768, "resid"), (24576, 512, 768, "gelu"), (25000, 512, 896, "dgelu")])
+def test_gemm_nt256_pipelined(M, N, K, epi):
+    """Shapes the dispatcher routes to the 256x256 global_load_lds kernel (gemm_nt256.hip): edge tiles in m and n, odd K-tile
+    counts, every fused epilogue; 10 repeats must be bit-identical (the pipeline's counted waits are race-free)."""
+    from protopformer_amd import ops
+    a = _mk((M, K), 0.5, 1).bfloat16(); b = _mk((N, K), 0.05, 2).bfloat16(); bias = _mk((N,), 0.1, 3)
+    pre = a.float() @ b.float().t()
+    if epi == "bf16":
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_BF16, bias=bias); ref = (pre + bias); tol = dict(rtol=8e-3, atol=2e-3)
+    elif epi == "resid":
+        res = _mk((M, N), 1.0, 4)
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_RESID, bias=bias, res=res); ref = res + pre + bias; tol = dict(rtol=1e-3, atol=2e-3)
+    elif epi == "gelu":
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_GELU, bias=bias, aux_out=aux); ref = torch.nn.functional.gelu(pre + bias); tol = dict(rtol=8e-3, atol=2e-3)
+    else:
+        gp = _mk((M, N), 0.5, 5).bfloat16()
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_DGELU, aux_in=gp); ref = pre * gp.float(); tol = dict(rtol=1e-2, atol=3e-3)
+    out = run()
+    assert_close(out.float(), ref, what=f"nt256 {epi}", **tol)
+    for _ in range(10):
+        assert torch.equal(out, run())
