@@ -5,6 +5,8 @@ hand-written kernel sequence below; weight gradients are accumulated by the kern
 buffer (param.grad views), so the node returns no parameter gradients to autograd.
 Reference call path: protopformer.py:141-173 (conv_features) -> deit:172-181, 209-240.
 """
+import os
+
 import torch
 
 from . import ops
@@ -108,11 +110,57 @@ def head_tokens_fwd(ppnet, store, x, idx):
 
 
 # ------------------------------------------------------------------------------------------------ DeiT backward
+class WgradLane:
+    """Second HIP stream for the weight-gradient GEMMs.  dW = dy^T x is off the critical path of backward (only the
+    optimizer consumes it), and the dgrad / LayerNorm / attention kernels of the chain rarely fill all 256 CUs, so the
+    wgrads run concurrently with them.  Hazards: a wgrad reads tensors produced on the main stream (the lane waits for the
+    main stream before each launch), temporaries may be freed while the lane still reads them (record_stream), and the
+    in-place bf16 gradient buffer is overwritten by the next LayerNorm backward (before_overwrite).  PPF_WGRAD_STREAM=0
+    runs everything on the main stream."""
+
+    def __init__(self, device):
+        self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
+        self.stream = torch.cuda.Stream(device=device) if self.enabled else None
+        self.last_read = {}
+
+    def submit(self, fn, reads):
+        if not self.enabled:
+            fn()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        for t in reads:
+            t.record_stream(self.stream)
+            self.last_read[t.data_ptr()] = done
+
+    def before_overwrite(self, t):
+        ev = self.last_read.pop(t.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.last_read.clear()
+
+
+def wgrad_lane(store):
+    lane = getattr(store, "_wgrad_lane", None)
+    if lane is None:
+        lane = store._wgrad_lane = WgradLane(store.device)
+    return lane
+
+
 def _wgrad(store, dy16, x16, weight, bias=None):
-    """dW[N,K] += dy^T x (split-K fp32 atomics into the flat grad), optional fused bias grad (column sums of dy)."""
+    """dW[N,K] += dy^T x (deterministic split-K into the flat grad), optional fused bias grad (column sums of dy); queued on
+    the weight-gradient lane."""
     gw = store.grad_view(weight)
-    ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
-             colsum=store.grad_view(bias) if bias is not None else None)
+    gb = store.grad_view(bias) if bias is not None else None
+    wgrad_lane(store).submit(lambda: ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
+                                              colsum=gb), (dy16, x16))
 
 
 def deit_backward(ppnet, store, saved, df):
@@ -126,6 +174,7 @@ def deit_backward(ppnet, store, saved, df):
     conv = ppnet.add_on_layers[0]
     Dp = conv.out_channels
     # add-on: sigmoid' then the two GEMMs
+    lane = wgrad_lane(store)
     dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), store.grad_view(conv.bias))
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
@@ -138,6 +187,7 @@ def deit_backward(ppnet, store, saved, df):
                       rows_per_group=N, dbias_next=store.grad_view(last.mlp.fc2.bias))
     gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
     if gs is not None:
+        lane.join()
         gs.chunk_ready(gs.tail_chunk)
     for i in range(len(layers) - 1, -1, -1):
         L, blk = layers[i], feats.blocks[i]
@@ -146,6 +196,7 @@ def deit_backward(ppnet, store, saved, df):
         dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
         _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
+        lane.before_overwrite(dyb)
         ops.layernorm_bwd(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
                           store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=N,
                           dbias_next=store.grad_view(blk.attn.proj.bias))
@@ -157,6 +208,7 @@ def deit_backward(ppnet, store, saved, df):
         dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
             prev = feats.blocks[i - 1]
+            lane.before_overwrite(dyb)
             ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
                               rows_per_group=N, dbias_next=store.grad_view(prev.mlp.fc2.bias))
@@ -164,12 +216,14 @@ def deit_backward(ppnet, store, saved, df):
             ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
+            lane.join()
             gs.chunk_ready(gs.block_chunk[i])
     # token assembly + patch embedding
     pe = feats.patch_embed
     Np = pe.num_patches
     dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(N, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
+    lane.join()
     if gs is not None:
         gs.chunk_ready(gs.head_chunk)
 

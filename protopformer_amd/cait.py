@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .backbone import LN_EPS, _dp, _wgrad, head_tokens_fwd
+from .backbone import LN_EPS, _dp, _wgrad, head_tokens_fwd, wgrad_lane
 from .deit import _Mlp, _PatchEmbed, _init_vit
 from .ops import EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID
 
@@ -229,6 +229,7 @@ def cait_backward(ppnet, store, saved, df):
     conv = ppnet.add_on_layers[0]
     Dp = conv.out_channels
     gv = store.grad_view
+    lane = wgrad_lane(store)
     dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), gv(conv.bias))
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
@@ -244,6 +245,7 @@ def cait_backward(ppnet, store, saved, df):
         ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dcls, cast_out=dyb, colscale=blk.gamma_2,
                           dbias_next=gv(blk.mlp.fc2.bias), branch=L["raw2"], dcolscale=gv(blk.gamma_2))
         dn2 = _mlp_bwd(store, blk, L, dyb)
+        lane.before_overwrite(dyb)
         ops.layernorm_bwd(dn2, L["cls1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dcls,
                           dx_out=dcls, cast_out=dyb, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias), branch=L["raw1"],
                           dcolscale=gv(blk.gamma_1))
@@ -276,6 +278,7 @@ def cait_backward(ppnet, store, saved, df):
     for i in range(len(sa) - 1, -1, -1):
         L, blk = sa[i], feats.blocks[i]
         dn2 = _mlp_bwd(store, blk, L, dyb)
+        lane.before_overwrite(dyb)
         ops.layernorm_bwd(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
                           cast_out=dyb, rowscale=L["s1"], rows_per_group=N, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias),
                           branch=L["raw1"], dcolscale=gv(blk.gamma_1))
@@ -286,16 +289,19 @@ def cait_backward(ppnet, store, saved, df):
         dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
             prev, Lp = feats.blocks[i - 1], sa[i - 1]
+            lane.before_overwrite(dyb)
             ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx,
                               dx_out=dx, cast_out=dyb, rowscale=Lp["s2"], rows_per_group=N, colscale=prev.gamma_2,
                               dbias_next=gv(prev.mlp.fc2.bias), branch=Lp["raw2"], dcolscale=gv(prev.gamma_2))
         else:
             ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
+            lane.join()
             gs.chunk_ready(gs.block_chunk[i])
     pe = feats.patch_embed
     dtok = ops.assemble_tokens_bwd(dx, gv(feats.pos_embed).reshape(N, D), None, B, N, D, 0)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
+    lane.join()
     if gs is not None:
         gs.chunk_ready(gs.head_chunk)
         gs.chunk_ready(gs.tail_chunk)

@@ -90,7 +90,7 @@ template <int NT> struct Geo { static constexpr int NW = NT > 4 ? 8 : 4, NTHR = 
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD, int NT>
-__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(Geo<NT>::NTHR, Geo<NT>::NW == 8 ? 4 : 2) void attn_fwd_kernel(const AttnParams p) {
     constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + NT * 32 * 4];
     unsigned char* tK = lds;
@@ -112,30 +112,36 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_fwd_kernel(const AttnPa
     bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
-    f32x16 s[NT];
-    float mx = -INFINITY;
-#pragma unroll
+    // Two passes over the keys instead of a 7-tile score strip in registers (112 VGPRs, one workgroup per CU): pass 1 only
+    // finds the row maximum, pass 2 recomputes each 32-key score tile, exponentiates it and feeds P.V at once.  The MFMA pipe
+    // is idle most of the time here; ~116 VGPRs let two workgroups share a CU so that one stages K/V while the other computes.
+    float mraw = -INFINITY;                      // max of the unscaled scores (scale > 0)
+#pragma unroll 1
     for (int t = 0; t < NT; ++t) {
+        f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[t][r] *= p.scale;
-            mx = fmaxf(mx, s[t][r]);
-        }
-        __builtin_amdgcn_sched_barrier(0);     // one tile's K fragments in flight at a time (register pressure)
+        for (int r = 0; r < 16; ++r) mraw = fmaxf(mraw, s[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+    const float mx = mraw * p.scale;
+    const float c1 = p.scale * 1.44269504088896340736f, m1 = mraw * c1;     // exp(x*scale - mx) = exp2(x*c1 - m1)
     float sum = 0.f;
     f32x16 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < NT; ++t) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int key0 = t * 32 + 8 * g + 4 * hh;
@@ -144,19 +150,18 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_fwd_kernel(const AttnPa
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float k = (key0 + i == qself) ? 1.0f : keep[i];
-                const float e = __expf(s[t][4 * g + i] - mx) * k;
+                const float e = __builtin_amdgcn_exp2f(s[4 * g + i] * c1 - m1) * k;
                 sum += e;
-                s[t][4 * g + i] = e + c;              // unnormalised probability (+eps/N); padded keys hit zero V rows
+                s[4 * g + i] = e + c;                 // unnormalised probability (+eps/N); padded keys hit zero V rows
             }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const bf16x8 pf = pack8(s[t], 8 * st);
+            const bf16x8 pf = pack8(s, 8 * st);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, t * 32 + 16 * st, dt * 32, lane), pf, o[dt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);     // keep the per-tile policy reads from being hoisted (register pressure)
     }
     sum += __shfl_xor(sum, 32, 64);
     const float zi = 1.0f / (sum + SOFTMAX_EPS);

@@ -16,11 +16,13 @@ _WORKSPACE = {}
 
 
 def _workspace(device, nbytes):
-    """Reusable split-K scratch (grown on demand, one per device)."""
-    buf = _WORKSPACE.get(device)
+    """Reusable split-K scratch, grown on demand: one per (device, stream) -- the weight-gradient lane (backbone.WgradLane)
+    runs its GEMMs on a second stream, concurrently with main-stream kernels that also use a workspace."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _WORKSPACE[device] = buf
+        _WORKSPACE[key] = buf
     return buf
 
 
