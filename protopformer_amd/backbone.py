@@ -65,14 +65,19 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     cls_attn = idx = None
     layers = []
     x = x.reshape(M, D)
+    lane = wgrad_lane(store)
     for i, blk in enumerate(feats.blocks):
         if i == reserve_layer:
+            lane.join()
             cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1)
         n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, N, D, policy=policy, self_keep=True)
         if i < reserve_layer:
-            ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
+            # only the rollout at `reserve_layer` consumes the head-mean maps: recompute them on the side stream, under the
+            # rest of this block
+            lane.submit(lambda qkv=qkv, rowmax=rowmax, zinv=zinv, i=i: ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy,
+                                                                                        self_keep=True, out=hm[i]), (qkv, rowmax, zinv, hm))
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N)
         n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
@@ -83,6 +88,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
             layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ao=ao, rowmax=rowmax, zinv=zinv, x1=x1, n2=n2,
                                mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2))
         x = x2
+    lane.join()
     return x.reshape(B, N, D), cls_attn, idx, layers
 
 
@@ -123,8 +129,8 @@ class WgradLane:
         self.stream = torch.cuda.Stream(device=device) if self.enabled else None
         self.last_read = {}
 
-    def submit(self, fn, reads):
-        if not self.enabled:
+    def submit(self, fn, reads, tag=None):
+        if not self.enabled or (tag is not None and os.environ.get("PPF_LANE_" + tag, "1") == "0"):
             fn()
             return
         self.stream.wait_stream(torch.cuda.current_stream())

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .backbone import DEIT_FNS, TokensFn, droppath_scales
+from .backbone import DEIT_FNS, TokensFn, droppath_scales, wgrad_lane
 from .deit import MyVisionTransformer
 from .flat import FlatStore
 
@@ -81,13 +81,21 @@ class ProtoLayerFn(torch.autograd.Function):
         store.attach_all_grads()
         B, T1, Dp = f.shape
         df = torch.zeros_like(f)
+        lane = wgrad_lane(store)      # prototype gradients feed only the optimizer: side stream, under the backbone backward
+        torch.autograd.Variable._execution_engine.queue_callback(lane.join)     # ... joined when this backward pass ends
         if g_l is not None or g_full is not None:
-            ops.proto_bwd(f, 1, T1 - 1, protos_local.reshape(-1, Dp), dist, g_full.contiguous() if g_full is not None else None,
-                          g_l.contiguous() if g_l is not None else None, argmax, df, store.grad_view(protos_local).reshape(-1, Dp),
-                          act_kind, ppnet.epsilon)
+            gf = g_full.contiguous() if g_full is not None else None
+            gl = g_l.contiguous() if g_l is not None else None
+            pl = protos_local.reshape(-1, Dp)
+            ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, df, None, act_kind, ppnet.epsilon)
+            lane.submit(lambda: ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, None, store.grad_view(protos_local).reshape(-1, Dp),
+                                              act_kind, ppnet.epsilon), [t for t in (f, dist, gf, gl, argmax) if t is not None], tag="PROTO")
         if g_g is not None:
-            ops.proto_bwd(f, 0, 1, protos_global.reshape(-1, Dp), dist_g, None, g_g.contiguous(), None, df,
-                          store.grad_view(protos_global).reshape(-1, Dp), act_kind, ppnet.epsilon)
+            gg = g_g.contiguous()
+            pg = protos_global.reshape(-1, Dp)
+            ops.proto_bwd(f, 0, 1, pg, dist_g, None, gg, None, df, None, act_kind, ppnet.epsilon)
+            lane.submit(lambda: ops.proto_bwd(f, 0, 1, pg, dist_g, None, gg, None, None, store.grad_view(protos_global).reshape(-1, Dp),
+                                              act_kind, ppnet.epsilon), (f, dist_g, gg), tag="PROTO")
         return df, None, None, None, None
 
 
