@@ -214,12 +214,19 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
                     make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
         const int col = (lane & 15) * 4;
         const int n = n0 + wn + col;
+        const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
+        EpiRow rr[8];
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int m = m0 + wm + 32 * mi + pass * 4 + (lane >> 4);
+            rr[pass] = epi_load_row<EPI>(p, m, n, m < p.M && n < p.N);
+        }
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
             const int r = pass * 4 + (lane >> 4);
             const int m = m0 + wm + 32 * mi + r;
             const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
-            if (m < p.M && n < p.N) epilogue4<EPI>(p, m, n, v.x, v.y, v.z, v.w);
+            if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
         }
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
@@ -342,6 +349,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
             case EPI_GELU: return launch<false, false, EPI_GELU, false>(p, 1, stream);
             case EPI_SIGMOID_F32: return launch<false, false, EPI_SIGMOID_F32, false>(p, 1, stream);
             case EPI_RESID: return launch<false, false, EPI_RESID, false>(p, 1, stream);
+            case EPI_DGELU: return launch<false, false, EPI_DGELU, false>(p, 1, stream);
             default: break;
         }
     } else if (!trans_a && trans_b) {

@@ -29,8 +29,43 @@ struct GemmParams {
     int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
 };
 
+// The fused epilogues work on 4 consecutive columns of one output row.  On gfx9 loads and stores share the vmcnt counter and
+// the compiler waits vmcnt(0) before it uses a loaded value whenever stores are pending too -- a load between two stores makes
+// every store wait for the previous one to reach L2.  So the per-column operands (bias, LayerScale) are loaded once per lane
+// (EpiCols), the per-row operands (residual, gelu', DropPath scale) of a whole batch of rows are loaded before that batch's
+// stores (EpiRow / epi_load_row), and epi_store itself issues no loads.
+struct EpiCols { float4 bias, colscale; };
+struct EpiRow { float4 res; uint2 aux; float rowscale; };
+
 template <int EPI>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, float v0, float v1, float v2, float v3) {
+__device__ __forceinline__ EpiCols epi_load_cols(const GemmParams& p, int n0, bool ok) {
+    EpiCols c;
+    c.bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    c.colscale = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (EPI != EPI_ATOMIC && EPI != EPI_PARTIAL) {
+        if (ok && p.bias) c.bias = *reinterpret_cast<const float4*>(p.bias + n0);
+        if constexpr (EPI == EPI_RESID) { if (ok && p.colscale) c.colscale = *reinterpret_cast<const float4*>(p.colscale + n0); }
+    }
+    return c;
+}
+
+template <int EPI>
+__device__ __forceinline__ EpiRow epi_load_row(const GemmParams& p, int m, int n0, bool ok) {
+    EpiRow r;
+    r.res = make_float4(0.f, 0.f, 0.f, 0.f); r.aux = make_uint2(0, 0); r.rowscale = 1.0f;
+    if constexpr (EPI == EPI_RESID) {
+        if (ok) {
+            r.res = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n0);
+            if (p.rowscale) r.rowscale = p.rowscale[m / p.rows_per_group];
+        }
+    } else if constexpr (EPI == EPI_DGELU) {
+        if (ok) r.aux = *reinterpret_cast<const uint2*>(p.aux_in + (size_t)m * p.ldaux + n0);
+    }
+    return r;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, float v0, float v1, float v2, float v3, const EpiCols& cc, const EpiRow& rr) {
     float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
     if constexpr (EPI == EPI_ATOMIC) {
         float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0;
@@ -43,10 +78,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
         *reinterpret_cast<float4*>(p.ws + p.zslice * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
         return;
     }
-    if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
+    v[0] += cc.bias.x; v[1] += cc.bias.y; v[2] += cc.bias.z; v[3] += cc.bias.w;
     if constexpr (EPI == EPI_BF16) {
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
             make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -65,21 +97,12 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n0, fl
     } else if constexpr (EPI == EPI_RESID) {
         if (p.aux_out)
             *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        if (p.colscale) {
-            const float4 g = *reinterpret_cast<const float4*>(p.colscale + n0);
-            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
-        }
-        if (p.rowscale) {
-            const float s = p.rowscale[m / p.rows_per_group];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= s;
-        }
-        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n0);
+        const float s = rr.rowscale;
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) =
-            make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
+            make_float4(rr.res.x + v[0] * cc.colscale.x * s, rr.res.y + v[1] * cc.colscale.y * s, rr.res.z + v[2] * cc.colscale.z * s,
+                        rr.res.w + v[3] * cc.colscale.w * s);
     } else if constexpr (EPI == EPI_DGELU) {
-        const uint2 h = *reinterpret_cast<const uint2*>(p.aux_in + (size_t)m * p.ldaux + n0);
-        const float2 h01 = unpack_bf16x2(h.x), h23 = unpack_bf16x2(h.y);
+        const float2 h01 = unpack_bf16x2(rr.aux.x), h23 = unpack_bf16x2(rr.aux.y);
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
             make_uint2(pack_bf16x2(v[0] * h01.x, v[1] * h01.y), pack_bf16x2(v[2] * h23.x, v[3] * h23.y));
     }

@@ -1,21 +1,25 @@
-// 256x256x64 bf16 MFMA GEMM for gfx950, both operands contraction-contiguous:
+// 256x256x64 bf16 MFMA GEMM for gfx950, both operands contraction-contiguous, persistent workgroups:
 //
-//   C[m][n] = epilogue( sum_k A[m*lda + k] * B[n*ldb + k] )          (x W^T forward GEMMs; dgrad through a W^T shadow)
+//   C[m][n] = epilogue( sum_k A[m*lda + k] * B[n*ldb + k] )          (x W^T forward GEMMs)
 //
-// One 512-thread workgroup (8 waves, 2 along m x 4 along n, 128x64 outputs per wave) per CU, 128 KiB of LDS:
+// One 512-thread workgroup (8 waves, 2 along m x 4 along n, 128x64 outputs per wave) per CU walks a strided list of
+// output tiles; the K-tile stream never drains between tiles:
 //
 //   * operands go global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass).  The LDS image of a
 //     128-row x 64-k half-tile is lane-linear, so the bank swizzle (16-byte chunk ^= (row>>1)&7) is applied to the per-lane
 //     SOURCE address and again on the fragment reads.
-//   * a K tile is four half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), double-buffered.  Each K tile is
-//     multiplied in four phases (one 64x32 accumulator quadrant of every wave x K=64 = 8 MFMA 32x32x16 per phase); every
-//     phase also issues one half-tile of a LATER K tile, into a slot whose last fragment read is >= 2 phases old.  Loads are
-//     retired with a counted s_waitcnt vmcnt(4) once per K tile (never 0 inside the loop), one phase before the first read.
+//   * a K tile is four half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), double-buffered (128 KiB).  Each K tile
+//     is multiplied in four phases (one 64x32 accumulator quadrant of every wave x K=64 = 8 MFMA 32x32x16 per phase); every
+//     phase also issues one half-tile of a LATER K tile -- of the next output tile near the end of this one -- into a slot
+//     whose last fragment read is >= 2 phases old.  Loads are retired with a counted s_waitcnt vmcnt(4) once per K tile
+//     (never 0 inside the loop), one phase before the first read.  Epilogue stores share the counter; loads retire in order
+//     among loads, so "at most 4 outstanding" still implies that everything older than the last two half-tiles has landed.
 //   * the two waves that share a SIMD (wave w and w+4: the two m-halves) run one barrier apart, so one of them is in its
 //     ds_read / load-issue half of a phase while the other is in its MFMA half.
-//
-// The fused epilogues are the ones of gemm_bf16.hip (gemm_common.h); the accumulators leave through per-wave LDS strips so that
-// stores, bias and residual accesses are full 256-byte row segments.
+//   * the fused epilogues (gemm_common.h) run at the tile boundary with the next tile's operands already in flight: each
+//     wave transposes its accumulators 16 rows at a time through a private 4 KiB LDS strip above the operand ring, so the
+//     stores are full 256-byte row segments and drain while the next tile is being multiplied.  The first m-half does this
+//     after the boundary barrier, the second before it: both epilogues fall into the same barrier interval.
 #include "gemm_common.h"
 #include <cstdlib>
 
@@ -25,8 +29,9 @@ using namespace ppfg;
 constexpr int TM = 256, TN = 256, TK = 64, NTHR = 512;
 constexpr int HALF = 128 * TK * 2;           // 16 KiB: one half-tile
 constexpr int BUFB = 4 * HALF;               // A0 A1 B0 B1 of one K tile
-constexpr int LDS_BYTES = 2 * BUFB;          // 128 KiB
-constexpr int SLD = 68;                      // fp32 pitch of the epilogue strip
+constexpr int RING = 2 * BUFB;               // 128 KiB
+constexpr int STRIP = 16 * 64 * 4;           // 4 KiB per wave: 16 rows x 64 fp32, float4 slot ^= row
+constexpr int LDS_BYTES = RING + 8 * STRIP;  // 160 KiB
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -34,34 +39,62 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #define NT_BAR() __builtin_amdgcn_s_barrier()
 #define NT_PIN() __builtin_amdgcn_sched_barrier(0)
 
+struct Tile {                    // uniform description of one output tile
+    const unsigned char* a;      // A + m0s * lda (bytes): first row of the (shifted) tile
+    const unsigned char* b;
+    int m_lo, n_lo;              // outputs below these belong to the previous tile (edge tiles are shifted to stay in range)
+    int m0s, n0s;                // shifted origin
+};
+
 struct Ctx {
-    const bf16_t* srcA[2][2];    // [half][instr] this thread's source chunk at k = 0 (swizzle applied)
-    const bf16_t* srcB[2][2];
+    Tile cur, nxt;
+    unsigned ta, tb;             // this thread's byte offset inside a 64-row x 64-k slab: (tid>>3) * ld * 2 + swizzled chunk * 16
+    unsigned sa, sb;             // 64 rows of A / B in bytes
     unsigned char* smem;
     int wave_off;                // wave * 1024: this wave's 64 x 16 B run inside an 8 KiB instruction slab
     int a_rd, b_rd;              // byte offsets of this wave's A / B fragment rows inside a K-tile buffer
     int rd[4];                   // per-lane swizzled offset of k-substep ks
-    int nt;
+    int nt;                      // K tiles per output tile (even)
+    bool has_next;               // this workgroup has another output tile after the current one
 };
 
-// one half-tile: 1024 chunks of 16 B, two per thread
-__device__ __forceinline__ void stage_half(const Ctx& c, unsigned char* slot, const bf16_t* const (&src)[2], int kt) {
+// Edge tiles are shifted back so that all 256 rows exist (M, N >= 256); the rows they share with the previous tile are
+// recomputed identically and masked out of the epilogue (m_lo / n_lo).
+__device__ __forceinline__ void tile_desc(const GemmParams& p, int vid, Tile& t) {
+    const int tiles_n = (p.N + TN - 1) / TN;
+    t.m_lo = (vid / tiles_n) * TM; t.n_lo = (vid % tiles_n) * TN;
+    t.m0s = min(t.m_lo, p.M - TM); t.n0s = min(t.n_lo, p.N - TN);
+    t.a = reinterpret_cast<const unsigned char*>(p.A) + (size_t)t.m0s * p.lda * 2;
+    t.b = reinterpret_cast<const unsigned char*>(p.B) + (size_t)t.n0s * p.ldb * 2;
+}
+
+// one half-tile (128 rows x 64 k): 1024 chunks of 16 B, two per thread (rows tid>>3 and 64 + tid>>3 of the half)
+__device__ __forceinline__ void stage_half(const Ctx& c, unsigned char* slot, const unsigned char* base, unsigned toff, unsigned s64, int half, int kt) {
+    const unsigned char* bk = base + (size_t)kt * (TK * 2) + (size_t)(2 * half) * s64;      // uniform
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + (size_t)kt * TK), (lds_void_t*)(slot + i * 8192 + c.wave_off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + (size_t)i * s64 + toff), (lds_void_t*)(slot + i * 8192 + c.wave_off), 16, 0, 0);
+}
+// K tile s of the stream that starts at the current output tile: s >= nt is K tile s - nt of the next output tile
+template <bool IS_A>
+__device__ __forceinline__ void stage_stream(const Ctx& c, unsigned char* slot, int half, int s) {
+    const Tile& t = s < c.nt ? c.cur : c.nxt;
+    const int kt = s < c.nt ? s : s - c.nt;
+    stage_half(c, slot, IS_A ? t.a : t.b, IS_A ? c.ta : c.tb, IS_A ? c.sa : c.sb, half, kt);
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// Multiply K tile u (resident in buffer BI).  TAIL = false: tiles u+1 and u+2 both exist (no bounds tests in the loop body).
+// Multiply K tile u (resident in buffer BI) up to the last MFMA of phase 4; the caller issues that phase's closing barrier.
+// TAIL = false: K tiles u+1 and u+2 are tiles of the current output tile (no tests in the loop body).
 template <int BI, bool TAIL>
 __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4]) {
     unsigned char* cur = c.smem + BI * BUFB;
     unsigned char* oth = c.smem + (BI ^ 1) * BUFB;
     const unsigned char* ca = cur + c.a_rd;
     const unsigned char* cb = cur + c.b_rd;
-    const bool more1 = !TAIL || (u + 1 < c.nt);
-    const bool more2 = !TAIL || (u + 2 < c.nt);
+    const bool more1 = !TAIL || (u + 1 < c.nt) || c.has_next;
+    const bool more2 = !TAIL || (u + 2 < c.nt) || c.has_next;
 
     // ---- phase 1: B sub-tiles 0/1 and A sub-tile 0 -> registers; quadrant (m 0-63, n 0-31)
 #pragma unroll
@@ -74,7 +107,8 @@ __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], 
         fa[0][ks] = lds_frag(ca + c.rd[ks]);
         fa[1][ks] = lds_frag(ca + 32 * 128 + c.rd[ks]);
     }
-    if (more1) stage_half(c, oth + 0 * HALF, c.srcA[0], u + 1);
+    if (!TAIL) stage_half(c, oth + 0 * HALF, c.cur.a, c.ta, c.sa, 0, u + 1);
+    else if (more1) stage_stream<true>(c, oth + 0 * HALF, 0, u + 1);
     NT_PIN(); NT_BAR(); NT_PIN();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -85,7 +119,8 @@ __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], 
     NT_PIN(); NT_BAR(); NT_PIN();
 
     // ---- phase 2: quadrant (m 0-63, n 32-63)
-    if (more1) stage_half(c, oth + 1 * HALF, c.srcA[1], u + 1);
+    if (!TAIL) stage_half(c, oth + 1 * HALF, c.cur.a, c.ta, c.sa, 1, u + 1);
+    else if (more1) stage_stream<true>(c, oth + 1 * HALF, 1, u + 1);
     NT_PIN(); NT_BAR(); NT_PIN();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -102,7 +137,8 @@ __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], 
         fa[0][ks] = lds_frag(ca + 64 * 128 + c.rd[ks]);
         fa[1][ks] = lds_frag(ca + 96 * 128 + c.rd[ks]);
     }
-    if (more2) stage_half(c, cur + 2 * HALF, c.srcB[0], u + 2);
+    if (!TAIL) stage_half(c, cur + 2 * HALF, c.cur.b, c.tb, c.sb, 0, u + 2);
+    else if (more2) stage_stream<false>(c, cur + 2 * HALF, 0, u + 2);
     NT_PIN(); NT_BAR(); NT_PIN();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -114,8 +150,11 @@ __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], 
 
     // ---- phase 4: quadrant (m 64-127, n 0-31).  Retire K tile u+1 (everything but the two half-tiles of u+2 just issued)
     // BEFORE this phase's first barrier; it is read from the next phase on.
-    if (more2) {
-        stage_half(c, cur + 3 * HALF, c.srcB[1], u + 2);
+    if (!TAIL) {
+        stage_half(c, cur + 3 * HALF, c.cur.b, c.tb, c.sb, 1, u + 2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (more2) {
+        stage_stream<false>(c, cur + 3 * HALF, 1, u + 2);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -127,7 +166,53 @@ __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], 
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[0][2 + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][ks], fa[f][ks], acc[0][2 + f], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
-    NT_PIN(); NT_BAR(); NT_PIN();
+    NT_PIN();
+}
+
+// Fused epilogue of one output tile.  After the MFMAs a lane holds, for each (ni, mi): row 32*mi+(lane&31) and, for g = 0..3,
+// the four consecutive columns 32*ni+8*g+4*(lane>>5).. (acc regs 4g..4g+3).  Each wave moves its 128x64 block 16 rows at a
+// time through its private strip so that 16 consecutive lanes cover one 64-column row segment; then re-zeroes the accumulators.
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, float* strip, int m0w, int n0w, int m_lo, int n_lo, int lane, f32x16 (&acc)[2][4]) {
+    const int l31 = lane & 31, hh = lane >> 5, r16 = l31 & 15;
+    const int col = (lane & 15) * 4;
+    const int n = n0w + col;
+    const EpiCols cc = epi_load_cols<EPI>(p, n, true);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            if ((l31 >> 4) == rh) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int slot = (8 * ni + 2 * g + hh) ^ r16;
+                        *reinterpret_cast<float4*>(strip + r16 * 64 + slot * 4) =
+                            make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+                    }
+            }
+            EpiRow rr[4];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0w + 32 * mi + 16 * rh + pass * 4 + (lane >> 4);
+                rr[pass] = epi_load_row<EPI>(p, m, n, m >= m_lo && n >= n_lo);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 4 + (lane >> 4);
+                const int m = m0w + 32 * mi + 16 * rh + r;
+                const float4 v = *reinterpret_cast<const float4*>(strip + r * 64 + (((lane & 15) ^ r) << 2));
+                if (m >= m_lo && n >= n_lo) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
 template <int EPI>
@@ -138,30 +223,30 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     const int wr = wave >> 2, wc = wave & 3;
 
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (vid / tiles_n) * TM, n0 = (vid % tiles_n) * TN;
+    const int ntiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int G = gridDim.x;
+    // round j of the persistent loop covers tiles [j*G, (j+1)*G); inside a round consecutive tiles (n fastest: one A panel)
+    // go to workgroups of the same XCD
+    int vid = xcd_remap(blockIdx.x, G);
+    if (vid >= ntiles) return;
 
     Ctx c;
     c.smem = smem;
     c.wave_off = wave * 1024;
     c.nt = p.K / TK;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = i * NTHR + tid;
-            const int r = q >> 3, ch = (q & 7) ^ ((r >> 1) & 7);
-            const int ra = min(m0 + h * 128 + r, p.M - 1), rb = min(n0 + h * 128 + r, p.N - 1);   // edge tiles re-read the last row
-            c.srcA[h][i] = p.A + (size_t)ra * p.lda + ch * 8;
-            c.srcB[h][i] = p.B + (size_t)rb * p.ldb + ch * 8;
-        }
     {
+        const int r = tid >> 3, ch = (tid & 7) ^ ((r >> 1) & 7);      // rows r and 64 + r of a half share the swizzle
+        c.ta = (unsigned)r * (unsigned)p.lda * 2u + ch * 16;
+        c.tb = (unsigned)r * (unsigned)p.ldb * 2u + ch * 16;
+        c.sa = 64u * (unsigned)p.lda * 2u;
+        c.sb = 64u * (unsigned)p.ldb * 2u;
         const int l31 = lane & 31, hh = lane >> 5, sw = (l31 >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c.rd[ks] = l31 * 128 + (((ks * 2 + hh) ^ sw) << 4);
     }
     c.a_rd = wr * HALF;
     c.b_rd = (2 + (wc >> 1)) * HALF + (wc & 1) * 64 * 128;
+    float* strip = reinterpret_cast<float*>(smem + RING + wave * STRIP);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -172,56 +257,45 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 fa[2][4], fb[2][4];
 
-    // prologue: K tile 0 complete, the B half-tiles of K tile 1 in flight
-    stage_half(c, smem + 2 * HALF, c.srcB[0], 0);
-    stage_half(c, smem + 3 * HALF, c.srcB[1], 0);
-    stage_half(c, smem + 0 * HALF, c.srcA[0], 0);
-    stage_half(c, smem + 1 * HALF, c.srcA[1], 0);
-    if (c.nt > 1) {
-        stage_half(c, smem + BUFB + 2 * HALF, c.srcB[0], 1);
-        stage_half(c, smem + BUFB + 3 * HALF, c.srcB[1], 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // prologue: K tile 0 of the first output tile complete, the B half-tiles of K tile 1 in flight
+    tile_desc(p, vid, c.cur);
+    c.nxt = c.cur;
+    stage_half(c, smem + 2 * HALF, c.cur.b, c.tb, c.sb, 0, 0);
+    stage_half(c, smem + 3 * HALF, c.cur.b, c.tb, c.sb, 1, 0);
+    stage_half(c, smem + 0 * HALF, c.cur.a, c.ta, c.sa, 0, 0);
+    stage_half(c, smem + 1 * HALF, c.cur.a, c.ta, c.sa, 1, 0);
+    stage_half(c, smem + BUFB + 2 * HALF, c.cur.b, c.tb, c.sb, 0, 1);
+    stage_half(c, smem + BUFB + 3 * HALF, c.cur.b, c.tb, c.sb, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     NT_PIN(); NT_BAR(); NT_PIN();
     if (wr == 1) { NT_BAR(); }                   // the second m-half runs one barrier behind the first
     NT_PIN();
 
-    int u = 0;
-    for (; u + 3 < c.nt; u += 2) {
-        ktile<0, false>(c, u, acc, fa, fb);
-        ktile<1, false>(c, u + 1, acc, fa, fb);
-    }
-    for (; u < c.nt; u += 2) {
-        ktile<0, true>(c, u, acc, fa, fb);
-        if (u + 1 < c.nt) ktile<1, true>(c, u + 1, acc, fa, fb);
-    }
-    if (wr == 0) { NT_BAR(); }                   // re-align the two halves: every fragment read has retired past this point
-    NT_PIN();
-
-    // epilogue: same strip transpose as gemm_bf16.hip (lane holds row wm+32*mi+(lane&31), columns wn+32*ni+8*g+4*(lane>>5)..+3)
-    const int hh = lane >> 5;
-    const int wm = wr * 128, wn = wc * 64;
-    float* strip = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(strip + (lane & 31) * SLD + 32 * ni + 8 * g + 4 * hh) =
-                    make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
-        const int col = (lane & 15) * 4;
-        const int n = n0 + wn + col;
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 4 + (lane >> 4);
-            const int m = m0 + wm + 32 * mi + r;
-            const float4 v = *reinterpret_cast<const float4*>(strip + r * SLD + col);
-            if (m < p.M && n < p.N) epilogue4<EPI>(p, m, n, v.x, v.y, v.z, v.w);
+    for (;;) {
+        const int nvid = vid + G;
+        c.has_next = nvid < ntiles;
+        if (c.has_next) tile_desc(p, nvid, c.nxt);
+        int u = 0;
+        for (; u + 3 < c.nt; u += 2) {
+            ktile<0, false>(c, u, acc, fa, fb);
+            NT_BAR(); NT_PIN();
+            ktile<1, false>(c, u + 1, acc, fa, fb);
+            NT_BAR(); NT_PIN();
         }
+        ktile<0, true>(c, u, acc, fa, fb);
+        NT_BAR(); NT_PIN();
+        ktile<1, true>(c, u + 1, acc, fa, fb);
+        // tile boundary: both m-halves run their epilogue in the barrier interval that follows the first half's last MFMA
+        const int m0 = c.cur.m0s + wr * 128, n0 = c.cur.n0s + wc * 64;
+        if (wr == 1) tile_epilogue<EPI>(p, strip, m0, n0, c.cur.m_lo, c.cur.n_lo, lane, acc);
+        NT_PIN(); NT_BAR(); NT_PIN();
+        if (wr == 0) tile_epilogue<EPI>(p, strip, m0, n0, c.cur.m_lo, c.cur.n_lo, lane, acc);
+        NT_PIN();
+        if (!c.has_next) break;
+        vid = nvid;
+        c.cur = c.nxt;
     }
+    if (wr == 0) { NT_BAR(); }                   // every wave executes the same number of barriers
 }
 
 template <int EPI>
@@ -234,7 +308,8 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), LDS_BYTES, stream, p);
+    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(NTHR), LDS_BYTES, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;
 }
@@ -251,7 +326,8 @@ bool nt256_eligible(const GemmParams& p, int epi) {
     static const int mode = getenv("PPF_GEMM_NT256") ? atoi(getenv("PPF_GEMM_NT256")) : -1;
     if (mode == 0) return false;
     if (!(epi == EPI_BF16 || epi == EPI_F32 || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU)) return false;
-    if (p.K % TK != 0 || p.K < 2 * TK || p.kpad) return false;
+    if (p.K % (2 * TK) != 0 || p.kpad) return false;                      // an even number of K tiles: buffer parity restarts per tile
+    if (p.M < TM || p.N < TN || (long long)p.lda * 256 >= (1ll << 30) || (long long)p.ldb * 256 >= (1ll << 30)) return false;
     const int tn = (p.N + TN - 1) / TN;
     const long long tiles = (long long)((p.M + TM - 1) / TM) * tn;
     if (mode == 1) return true;
