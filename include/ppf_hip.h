@@ -68,7 +68,13 @@ int ppf_layernorm_fwd(const float* x, const int* row_map, const float* w, const 
 int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const float* w, const float* mean, const float* rstd,
                       const float* dres_in, float* dx_out, float* dw, float* db, void* cast_out, const float* rowscale,
                       int rows_per_group, const float* colscale, float* dbias_next, const void* branch, float* dcolscale,
-                      int rows, int D, ppf_stream_t stream);
+                      int rows, int D, float* partial, size_t partial_bytes, ppf_stream_t stream);
+/* partial != NULL: the column sums (dw, db, dbias_next, dcolscale) are NOT accumulated by ppf_layernorm_bwd; each workgroup
+ * writes its partial sums into partial[ppf_layernorm_bwd_blocks(rows)][4][D] (the last rows are second-level scratch) and ppf_layernorm_bwd_reduce adds them up in a
+ * fixed order (deterministic, no float atomics; may run on another stream).  partial == NULL: fp32 atomics. */
+int ppf_layernorm_bwd_blocks(int rows);
+int ppf_layernorm_bwd_reduce(const float* partial, int rows, int D, float* dw, float* db, float* dbias_next, float* dcolscale,
+                             ppf_stream_t stream);
 
 /* ---- attention with the policy softmax (deit:29-60; class attention cait:50-90 with self_keep = 0) -------------
  * qkv bf16 [B*N][3D] packed q|k|v, head h at columns h*hd.  policy [B][N] in {0,1} or NULL.

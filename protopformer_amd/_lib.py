@@ -14,7 +14,8 @@ SIGS = {
     "ppf_gemm_bf16": "pppiiiiiiiiippipipppipf" "pz" "s",
     "ppf_device_info": "pppi",
     "ppf_layernorm_fwd": "ppppppp" "iif" "s",
-    "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "s",
+    "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "pz" "s",
+    "ppf_layernorm_bwd_reduce": "p" "ii" "pppp" "s",
     "ppf_cast_f32_bf16": "ppls",
     "ppf_im2col_patch": "ppiiiiis",
     "ppf_assemble_tokens": "ppppiiiis",
@@ -58,6 +59,8 @@ def lib():
         _lib.ppf_abi_version.restype = ctypes.c_int
         _lib.ppf_gemm_workspace_bytes.restype = ctypes.c_size_t
         _lib.ppf_gemm_workspace_bytes.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int
+        _lib.ppf_layernorm_bwd_blocks.argtypes = [ctypes.c_int]
         for name, spec in SIGS.items():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_int

@@ -5,6 +5,7 @@ hand-written kernel sequence below; weight gradients are accumulated by the kern
 buffer (param.grad views), so the node returns no parameter gradients to autograd.
 Reference call path: protopformer.py:141-173 (conv_features) -> deit:172-181, 209-240.
 """
+import functools
 import os
 
 import torch
@@ -13,6 +14,7 @@ from . import ops
 from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, EPI_SIGMOID_F32
 
 LN_EPS = 1e-6
+_KEEP_CACHE = {}
 
 
 def droppath_scales(rates, B, device, training):
@@ -22,7 +24,10 @@ def droppath_scales(rates, B, device, training):
     active = [i for i, r in enumerate(slots) if r > 0.0]
     if not active:
         return None, [-1] * len(slots)
-    keep = torch.tensor([1.0 - slots[i] for i in active], device=device, dtype=torch.float32)[:, None]
+    key = (tuple(slots), str(device))
+    keep = _KEEP_CACHE.get(key)
+    if keep is None:            # the H2D copy of a fresh host tensor is a blocking call: build the constant once per schedule
+        keep = _KEEP_CACHE[key] = torch.tensor([1.0 - slots[i] for i in active], device=device, dtype=torch.float32)[:, None]
     u = torch.rand(len(active), B, device=device, dtype=torch.float32)
     scales = (torch.floor(keep + u) / keep).contiguous()
     index = [-1] * len(slots)
@@ -181,6 +186,7 @@ def deit_backward(ppnet, store, saved, df):
     Dp = conv.out_channels
     # add-on: sigmoid' then the two GEMMs
     lane = wgrad_lane(store)
+    lnb = functools.partial(ops.layernorm_bwd, lane=lane)      # column-sum reductions (parameter grads) go to the side stream
     dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), store.grad_view(conv.bias))
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
@@ -188,7 +194,7 @@ def deit_backward(ppnet, store, saved, df):
     dx = torch.zeros((M, D), dtype=torch.float32, device=dev)
     dyb = torch.zeros((M, D), dtype=torch.bfloat16, device=dev)
     last = feats.blocks[-1]
-    ops.layernorm_bwd(dnf, x_last.reshape(M, D), feats.norm.weight, head["meanf"], head["rstdf"], store.grad_view(feats.norm.weight),
+    lnb(dnf, x_last.reshape(M, D), feats.norm.weight, head["meanf"], head["rstdf"], store.grad_view(feats.norm.weight),
                       store.grad_view(feats.norm.bias), dx_out=dx, row_map=head["row_map"], cast_out=dyb, rowscale=layers[-1]["s2"],
                       rows_per_group=N, dbias_next=store.grad_view(last.mlp.fc2.bias))
     gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
@@ -203,7 +209,7 @@ def deit_backward(ppnet, store, saved, df):
         _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
         lane.before_overwrite(dyb)
-        ops.layernorm_bwd(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
+        lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
                           store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=N,
                           dbias_next=store.grad_view(blk.attn.proj.bias))
         # attention branch: x1 = x + s1 * (attn(n1) Wp^T + bp)
@@ -215,11 +221,11 @@ def deit_backward(ppnet, store, saved, df):
         if i > 0:
             prev = feats.blocks[i - 1]
             lane.before_overwrite(dyb)
-            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
+            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
                               rows_per_group=N, dbias_next=store.grad_view(prev.mlp.fc2.bias))
         else:
-            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
+            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.join()

@@ -6,6 +6,8 @@ block ``reserve_layer`` (cait:326-339).  Parameter names equal the reference's (
 proj_l,proj_w},norm2,mlp.{fc1,fc2}}``, ``blocks_token_only.{i}.{gamma_1,gamma_2,norm1,attn.{q,k,v,proj},norm2,mlp}``, ``pos_embed``
 ``(1,Np,D)``, ``cls_token``, ``norm``).  nn modules are parameter containers only; all arithmetic is in csrc/cait.hip + the GEMMs.
 """
+import functools
+
 import torch
 import torch.nn as nn
 
@@ -230,11 +232,12 @@ def cait_backward(ppnet, store, saved, df):
     Dp = conv.out_channels
     gv = store.grad_view
     lane = wgrad_lane(store)
+    lnb = functools.partial(ops.layernorm_bwd, lane=lane)      # column-sum reductions (parameter grads) go to the side stream
     dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), gv(conv.bias))
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
     du = torch.zeros((B * N1, D), dtype=torch.float32, device=dev)
-    ops.layernorm_bwd(dnf, u_last.reshape(B * N1, D), feats.norm.weight, head["meanf"], head["rstdf"], gv(feats.norm.weight),
+    lnb(dnf, u_last.reshape(B * N1, D), feats.norm.weight, head["meanf"], head["rstdf"], gv(feats.norm.weight),
                       gv(feats.norm.bias), dx_out=du, row_map=head["row_map"])
     du3 = du.reshape(B, N1, D)
     dcls = du3[:, 0].contiguous()
@@ -242,11 +245,11 @@ def cait_backward(ppnet, store, saved, df):
     for j in range(len(ca) - 1, -1, -1):
         L, blk = ca[j], feats.blocks_token_only[j]
         dyb = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
-        ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dcls, cast_out=dyb, colscale=blk.gamma_2,
+        lnb(None, None, None, None, None, None, None, dres_in=dcls, cast_out=dyb, colscale=blk.gamma_2,
                           dbias_next=gv(blk.mlp.fc2.bias), branch=L["raw2"], dcolscale=gv(blk.gamma_2))
         dn2 = _mlp_bwd(store, blk, L, dyb)
         lane.before_overwrite(dyb)
-        ops.layernorm_bwd(dn2, L["cls1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dcls,
+        lnb(dn2, L["cls1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dcls,
                           dx_out=dcls, cast_out=dyb, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias), branch=L["raw1"],
                           dcolscale=gv(blk.gamma_1))
         _wgrad(store, dyb, L["out"], blk.attn.proj.weight)
@@ -263,23 +266,23 @@ def cait_backward(ppnet, store, saved, df):
         dnq = ops.gemm(dq, store.w16(blk.attn.q.weight), trans_b=True, epi=EPI_F32)
         dn16 = ops.merge3_cast(dnk, dnv, dnq, N1)
         du3[:, 0].copy_(dcls)                               # gradient reaching this block's cls input through the residual path
-        ops.layernorm_bwd(dn16, L["u"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=du, dx_out=du)
+        lnb(dn16, L["u"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=du, dx_out=du)
         dcls = du3[:, 0].contiguous()
     # cls_token parameter: sum over the batch of the cls gradient (column sums via the scale/cast pass)
     scratch = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
-    ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dcls, cast_out=scratch, dbias_next=gv(feats.cls_token).reshape(D))
+    lnb(None, None, None, None, None, None, None, dres_in=dcls, cast_out=scratch, dbias_next=gv(feats.cls_token).reshape(D))
     # ---- talking-heads blocks (reverse)
     dx = du3[:, 1:].contiguous().reshape(M, D)
     dyb = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
     last = feats.blocks[-1]
-    ops.layernorm_bwd(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
+    lnb(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
                       colscale=last.gamma_2, dbias_next=gv(last.mlp.fc2.bias), branch=sa[-1]["raw2"], dcolscale=gv(last.gamma_2))
     gs = getattr(ppnet, "_grad_sync", None)
     for i in range(len(sa) - 1, -1, -1):
         L, blk = sa[i], feats.blocks[i]
         dn2 = _mlp_bwd(store, blk, L, dyb)
         lane.before_overwrite(dyb)
-        ops.layernorm_bwd(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
+        lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
                           cast_out=dyb, rowscale=L["s1"], rows_per_group=N, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias),
                           branch=L["raw1"], dcolscale=gv(blk.gamma_1))
         _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
@@ -290,11 +293,11 @@ def cait_backward(ppnet, store, saved, df):
         if i > 0:
             prev, Lp = feats.blocks[i - 1], sa[i - 1]
             lane.before_overwrite(dyb)
-            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx,
+            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx,
                               dx_out=dx, cast_out=dyb, rowscale=Lp["s2"], rows_per_group=N, colscale=prev.gamma_2,
                               dbias_next=gv(prev.mlp.fc2.bias), branch=Lp["raw2"], dcolscale=gv(prev.gamma_2))
         else:
-            ops.layernorm_bwd(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
+            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.join()
             gs.chunk_ready(gs.block_chunk[i])

@@ -60,6 +60,7 @@ struct LnBwdParams {
     bf16_t* cast_out; const float* rowscale; int rows_per_group; const float* colscale; float* dbias_next;
     const bf16_t* branch; float* dcolscale;
     int rows, D;
+    float* partial;          // [gridDim.x][4][D] per-workgroup column sums (dw, db, dbias_next, dcolscale) or null: atomics
 };
 
 // dx_out[src] = dres_in[src] + LN'(dy);  dw += sum dy*xhat;  db += sum dy;
@@ -137,8 +138,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
         }
     }
     // workgroup reduction of the column partial sums, then one atomic per column per workgroup
-    auto flush = [&](float2 (&a)[NJ], float* dst) {
+    auto flush = [&](float2 (&a)[NJ], float* dst, int which) {
         if (!dst) return;
+        float* part = p.partial ? p.partial + ((size_t)blockIdx.x * 4 + which) * D : nullptr;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { red[wave][(j * 64 + lane) * 2] = a[j].x; red[wave][(j * 64 + lane) * 2 + 1] = a[j].y; }
@@ -150,12 +152,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
                 float s = 0.f;
 #pragma unroll
                 for (int wv_ = 0; wv_ < WAVES; ++wv_) s += red[wv_][i];
-                unsafeAtomicAdd(dst + c, s);
+                if (part) part[c] = s; else unsafeAtomicAdd(dst + c, s);
             }
         }
     };
-    if (p.dy) { flush(adw, p.dw); flush(adb, p.db); }
-    if (p.cast_out) { flush(anb, p.dbias_next); if (p.branch) flush(acs, p.dcolscale); }
+    if (p.dy) { flush(adw, p.dw, 0); flush(adb, p.db, 1); }
+    if (p.cast_out) { flush(anb, p.dbias_next, 2); if (p.branch) flush(acs, p.dcolscale, 3); }
 }
 
 // Bandwidth-oriented variant for D = 32*V*NJ (V = 4: D % 128 == 0, V = 2: D % 64 == 0): half a wavefront per row, so a
@@ -267,8 +269,9 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
             }
         }
     }
-    auto flush = [&](float (&a)[NJ][V], float* dst) {
+    auto flush = [&](float (&a)[NJ][V], float* dst, int which) {
         if (!dst) return;
+        float* part = p.partial ? p.partial + ((size_t)blockIdx.x * 4 + which) * D : nullptr;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -283,12 +286,48 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
 #pragma unroll
             for (int w_ = 0; w_ < WAVES; ++w_) s += red[w_][i];
             const int j = i / (32 * V), rem = i % (32 * V);
-            unsafeAtomicAdd(dst + 32 * V * j + rem, s);                      // column = V*l32 + e + 32*V*j
+            if (part) part[32 * V * j + rem] = s;                            // column = V*l32 + e + 32*V*j
+            else unsafeAtomicAdd(dst + 32 * V * j + rem, s);
         }
     };
-    if (p.dy) { flush(adw, p.dw); flush(adb, p.db); }
-    if (p.cast_out) { flush(anb, p.dbias_next); if (p.branch) flush(acs, p.dcolscale); }
+    if (p.dy) { flush(adw, p.dw, 0); flush(adb, p.db, 1); }
+    if (p.cast_out) { flush(anb, p.dbias_next, 2); if (p.branch) flush(acs, p.dcolscale, 3); }
 }
+
+// dst[c] += sum over workgroups of partial[wg][which][c], in a fixed order (deterministic; replaces ~1.8M fp32 atomics on 1152
+// addresses per LayerNorm backward).  Two levels: LN_RS slices of the workgroup axis are summed by
+// grid (ceil(D/64), 4 arrays, LN_RS) blocks of 16 row groups x 64 columns into partial2[LN_RS][4][D]; a second launch adds the slices.
+constexpr int LN_RS = 16;
+__global__ __launch_bounds__(1024) void ln_colsum_reduce1_kernel(const float* __restrict__ partial, float* __restrict__ partial2, int nblocks, int D,
+                                                                   unsigned present) {
+    __shared__ float red[16][64];
+    const int which = blockIdx.y, z = blockIdx.z;
+    if (!((present >> which) & 1u)) return;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int chunk = (nblocks + LN_RS - 1) / LN_RS, b0 = z * chunk, b1 = min(nblocks, b0 + chunk);
+    float s = 0.f;
+    if (c < D)
+        for (int b = b0 + g; b < b1; b += 16) s += partial[((size_t)b * 4 + which) * D + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        partial2[((size_t)z * 4 + which) * D + c] = t;
+    }
+}
+__global__ __launch_bounds__(256) void ln_colsum_reduce2_kernel(const float* __restrict__ partial2, int D, float* d0, float* d1, float* d2, float* d3) {
+    const int which = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    float* dst = which == 0 ? d0 : which == 1 ? d1 : which == 2 ? d2 : d3;
+    if (!dst || c >= D) return;
+    float t = 0.f;
+#pragma unroll
+    for (int z = 0; z < LN_RS; ++z) t += partial2[((size_t)z * 4 + which) * D + c];
+    dst[c] += t;
+}
+
+int ln_bwd_grid(int rows) { const int g = (rows + WAVES * 8 - 1) / (WAVES * 8); return g < 2048 ? g : 2048; }
 
 template <typename F>
 int dispatch_nj(int D, F&& f) {
@@ -324,14 +363,17 @@ int ppf_layernorm_fwd(const float* x, const int* row_map, const float* w, const 
 int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const float* w, const float* mean, const float* rstd,
                       const float* dres_in, float* dx_out, float* dw, float* db, void* cast_out, const float* rowscale,
                       int rows_per_group, const float* colscale, float* dbias_next, const void* branch, float* dcolscale,
-                      int rows, int D, hipStream_t stream) {
+                      int rows, int D, float* partial, size_t partial_bytes, hipStream_t stream) {
     PPF_CHECK_ARG(rows > 0 && D > 0 && (D % 2) == 0 && D <= 128 * MAXJ, PPF_ERR_SHAPE, "ppf_layernorm_bwd: bad shape rows=%d D=%d", rows, D);
     PPF_CHECK_ARG(dy != nullptr || dres_in != nullptr, PPF_ERR_ARG, "ppf_layernorm_bwd: need dy or dres_in");
     LnBwdParams p;
     p.dy = (const bf16_t*)dy; p.x = x; p.row_map = row_map; p.w = w; p.mean = mean; p.rstd = rstd; p.dres_in = dres_in; p.dx_out = dx_out;
     p.dw = dw; p.db = db; p.cast_out = (bf16_t*)cast_out; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.dbias_next = dbias_next; p.branch = (const bf16_t*)branch; p.dcolscale = dcolscale; p.rows = rows; p.D = D;
-    const int grid = min((rows + WAVES * 8 - 1) / (WAVES * 8), 2048);      // >= 8 rows per wave: amortise the column atomics
+    const int grid = ln_bwd_grid(rows);                                    // >= 8 rows per wave: amortise the column flush
+    PPF_CHECK_ARG(partial == nullptr || partial_bytes >= (size_t)(grid + LN_RS) * 4 * D * sizeof(float), PPF_ERR_ARG,
+                  "ppf_layernorm_bwd: partial-sum workspace needs ppf_layernorm_bwd_blocks(rows)*4*D*4 = %zu bytes", (size_t)(grid + LN_RS) * 4 * D * sizeof(float));
+    p.partial = partial;
 #define PPF_LN2(V, NJ) { hipLaunchKernelGGL((ln_bwd2_kernel<V, NJ>), dim3(grid), dim3(256), 0, stream, p); PPF_LAUNCH_CHECK(); return 0; }
     if (D % 128 == 0 && D <= 512) { switch (D / 128) { case 1: PPF_LN2(4, 1) case 2: PPF_LN2(4, 2) case 3: PPF_LN2(4, 3) case 4: PPF_LN2(4, 4) } }
     if (D % 64 == 0 && D <= 512) { switch (D / 64) { case 1: PPF_LN2(2, 1) case 3: PPF_LN2(2, 3) case 5: PPF_LN2(2, 5) case 7: PPF_LN2(2, 7) } }
@@ -341,6 +383,22 @@ int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const 
         PPF_LAUNCH_CHECK();
         return 0;
     });
+}
+
+// Rows of the partial-sum workspace for `rows` rows (workgroups + second-level slices): it holds blocks * 4 * D floats.
+int ppf_layernorm_bwd_blocks(int rows) { return ln_bwd_grid(rows) + LN_RS; }
+
+// Second half of ppf_layernorm_bwd(partial != NULL): dw / db / dbias_next / dcolscale += column sums of the per-workgroup partials
+// (pass the same pointers, NULL where ppf_layernorm_bwd got NULL).  May run on another stream once the first half is complete.
+int ppf_layernorm_bwd_reduce(const float* partial, int rows, int D, float* dw, float* db, float* dbias_next, float* dcolscale, hipStream_t stream) {
+    PPF_CHECK_ARG(partial && rows > 0 && D > 0, PPF_ERR_ARG, "ppf_layernorm_bwd_reduce: bad arguments");
+    const int nb = ln_bwd_grid(rows);
+    float* partial2 = const_cast<float*>(partial) + (size_t)nb * 4 * D;
+    const unsigned present = (dw ? 1u : 0u) | (db ? 2u : 0u) | (dbias_next ? 4u : 0u) | (dcolscale ? 8u : 0u);
+    hipLaunchKernelGGL(ln_colsum_reduce1_kernel, dim3((D + 63) / 64, 4, LN_RS), dim3(1024), 0, stream, partial, partial2, nb, D, present);
+    hipLaunchKernelGGL(ln_colsum_reduce2_kernel, dim3((D + 255) / 256, 4), dim3(256), 0, stream, partial2, D, dw, db, dbias_next, dcolscale);
+    PPF_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

@@ -1,4 +1,6 @@
 """Thin host-side wrappers over the C-ABI kernels (no arithmetic here: allocation, shapes, launch)."""
+import os
+
 import torch
 
 from . import _lib
@@ -80,15 +82,29 @@ def layernorm_fwd(x, w, b, eps=1e-6, row_map=None):
 
 
 def layernorm_bwd(dy, x, w, mean, rstd, dw, db, *, dres_in=None, dx_out=None, row_map=None, cast_out=None, rowscale=None,
-                  rows_per_group=1, colscale=None, dbias_next=None, branch=None, dcolscale=None):
-    """dx_out[src] = dres_in[src] + LN'(dy); dw/db accumulate (+=). dy=None: pure scale/cast/colsum pass."""
+                  rows_per_group=1, colscale=None, dbias_next=None, branch=None, dcolscale=None, lane=None):
+    """dx_out[src] = dres_in[src] + LN'(dy); dw/db accumulate (+=). dy=None: pure scale/cast/colsum pass.
+    Large calls write per-workgroup column partials and add them up in a second, deterministic kernel; with `lane`
+    (backbone.WgradLane) that reduction -- parameter gradients only -- runs on the side stream."""
     D = x.shape[-1] if x is not None else dres_in.shape[-1]
     if dy is not None:
         rows = dy.numel() // D
     else:
         rows = dres_in.numel() // D
+    sums = (dw if dy is not None else None, db if dy is not None else None, dbias_next if cast_out is not None else None,
+            dcolscale if (cast_out is not None and branch is not None) else None)
+    part = None
+    if rows >= 4096 and any(t is not None for t in sums) and os.environ.get("PPF_LN_PARTIAL", "1") != "0":
+        dev = (dy if dy is not None else dres_in).device
+        part = torch.empty(_lib.lib().ppf_layernorm_bwd_blocks(rows) * 4 * D, dtype=torch.float32, device=dev)
     _lib.call("ppf_layernorm_bwd", dy, x, row_map, w, mean, rstd, dres_in, dx_out, dw, db, cast_out, rowscale, rows_per_group,
-              colscale, dbias_next, branch, dcolscale, rows, D)
+              colscale, dbias_next, branch, dcolscale, rows, D, part, part.numel() * 4 if part is not None else 0)
+    if part is not None:
+        red = lambda: _lib.call("ppf_layernorm_bwd_reduce", part, rows, D, *sums)
+        if lane is not None:
+            lane.submit(red, (part,))
+        else:
+            red()
 
 
 def cast_bf16(src, dst=None):

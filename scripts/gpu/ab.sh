@@ -1,4 +1,1 @@
-for i in 1 2; do
-timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c90-200
-PPF_LANE_PROTO=0 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c90-200
-done
+timeout 600 python scripts/gpu/host_time.py 2>&1 | tail -45 | cut -c1-160
