@@ -1,1 +1,1 @@
-timeout 600 python scripts/gpu/host_time.py 2>&1 | tail -45 | cut -c1-160
+timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1

@@ -198,3 +198,58 @@ def test_micro_cait_backbone_grads_vs_oracle():
     assert len(rows) > 80
     bad = {k: v for k, v in rows.items() if v[1] < 0.98}
     assert not bad, bad
+
+
+def test_real_shape_cait_xxs24_train_step_vs_oracle():
+    """cait_xxs24_224 architecture (24 talking-heads + 2 class-attention blocks, D=192), B=2: losses vs the fp32 CPU oracle following
+    the same reservation, then every backbone gradient on a max-pool-free loss."""
+    from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
+    arch = "cait_xxs24_224"
+    cfg = O.make_cfg(arch, 200, 64, 20, 1, 121, global_per_class=5)
+    sd = O.init_state_dict(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    for k_ in sd:
+        if k_.endswith(".bias") and "add_on" not in k_:
+            sd[k_] = 0.05 * torch.randn(sd[k_].shape, generator=g)
+        if "qkv.weight" in k_:
+            sd[k_] = sd[k_] * 6.0                               # peaky attention => a well-separated top-k
+    m = construct_PPNet(arch, pretrained=False, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[cfg["reserve_layer"]],
+                        reserve_token_nums=[cfg["reserve_k"]], use_global=True, use_ppc_loss=True, global_proto_per_class=5,
+                        add_on_layers_type="regular")
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    for blk in m.features.blocks:
+        blk.drop_path_rate = 0.0
+    img = torch.randn(2, 3, 224, 224, generator=g); label = torch.tensor([3, 17])
+    logits, aux = m(img.cuda())
+    ce = CrossEntropyLoss()(logits, label.cuda())
+    cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label.cuda())
+    (ce + 0.1 * cov + 0.5 * mean).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad and p.grad is not None)
+    my_idx = m._ppc_cache[1].cpu().long()
+    with torch.no_grad():
+        out = O.ppnet_forward(sd, img, cfg, train=True, force_idx=my_idx)
+        _, parts = O.train_loss(out, label, cfg, with_ppc=True)
+    # bf16 operands through 26 blocks: tolerances as in the DeiT real-shape test
+    assert rel_err(logits, out["logits"]) < 5e-2
+    assert rel_err(ce, parts["ce"]) < 3e-2 and rel_err(cov, parts["ppc_cov"]) < 8e-2 and rel_err(mean, parts["ppc_mean"]) < 8e-2
+    m.flat_store().zero_grad()
+    f, _, idx = m._tokens(img.cuda())
+    w = torch.randn(f.shape, generator=g)
+    (f * w.cuda()).sum().backward()
+    params = {k: v.clone().requires_grad_(k not in O.FROZEN_KEYS) for k, v in sd.items()}
+    out = O.ppnet_forward(params, img, cfg, train=True, force_idx=idx.cpu().long())
+    fo = torch.cat([out["cls_tokens"], out["tokens"]], dim=1)
+    assert rel_err(f, fo) < 8e-2
+    (fo * w).sum().backward()
+    cosines = {}
+    for name, p in m.named_parameters():
+        if not p.requires_grad or params[name].grad is None:
+            continue
+        gm, gr = p.grad.float().cpu().reshape(-1), params[name].grad.reshape(-1)
+        if float(gr.abs().max()) < 1e-10 or name.endswith("proj_l.bias") or name.endswith("attn.k.bias"):
+            continue
+        cosines[name] = float(torch.dot(gm, gr) / (gm.norm() * gr.norm()).clamp_min(1e-30))
+    assert len(cosines) > 300
+    bad = {k: v for k, v in cosines.items() if v < 0.97}
+    assert not bad, bad
