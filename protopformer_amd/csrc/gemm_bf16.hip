@@ -296,9 +296,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int pick_splitk(int M, int N, int K) {
-    // wgrad-style problems (small output, very long contraction): spread over ~2 workgroups per CU
+    // wgrad-style problems (small output, very long contraction)
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int s = (512 + tiles - 1) / tiles;
+    // K slices: alone on the GPU the kernel is fastest with as many slices as fit in ONE round of 3 workgroups per CU (768:
+    // -17 % vs 540; one slice more spills into a second round and gives it all back).  In the train step these GEMMs run on
+    // the side stream under the dgrad chain, where a smaller footprint wins (step time: 432 <= 540 < 768), so that is the default.
+    static const int target = getenv("PPF_SPLITK_TARGET") ? atoi(getenv("PPF_SPLITK_TARGET")) : 432;
+    int s = target / tiles;
     const int maxs = (K + 4 * BK - 1) / (4 * BK);      // at least 4 K-tiles per slice
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
