@@ -63,27 +63,46 @@ __global__ __launch_bounds__(256) void proto_fwd_kernel(const ProtoFwdParams p) 
 #pragma unroll
     for (int t = 0; t < TT; ++t) x2p[t] = 0.f;
 
-    for (int k0 = 0; k0 < p.Dp; k0 += BKF) {
-        __syncthreads();
-        for (int i = tid; i < (ROWS + PB) * (BKF / 4); i += 256) {
+    // operand chunks go global -> registers -> LDS; the loads of chunk k+1 are issued before chunk k is multiplied
+    constexpr int NLD = ((ROWS + PB) * (BKF / 4) + 255) / 256;
+    float4 stg[NLD];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256;
             const int row = i / (BKF / 4), c4 = i % (BKF / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < ROWS) {
-                if (row < nrows && k0 + c4 * 4 < p.Dp) {
-                    const float* src = POOL ? p.tok + (size_t)grp * p.stride_b + (size_t)(p.t0 + row) * p.Dp
-                                            : p.tok + (size_t)(grp * ROWS + row) * p.stride_b + (size_t)p.t0 * p.Dp;
-                    v = *reinterpret_cast<const float4*>(src + k0 + c4 * 4);
+            if (i < (ROWS + PB) * (BKF / 4) && k0 + c4 * 4 < p.Dp) {
+                if (row < ROWS) {
+                    if (row < nrows) {
+                        const float* src = POOL ? p.tok + (size_t)grp * p.stride_b + (size_t)(p.t0 + row) * p.Dp
+                                                : p.tok + (size_t)(grp * ROWS + row) * p.stride_b + (size_t)p.t0 * p.Dp;
+                        v = *reinterpret_cast<const float4*>(src + k0 + c4 * 4);
+                    }
+                } else if (p0 + row - ROWS < p.P) {
+                    v = *reinterpret_cast<const float4*>(p.protos + (size_t)(p0 + row - ROWS) * p.Dp + k0 + c4 * 4);
                 }
-                float* d = ltok + row * LDP + c4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            } else {
-                const int pr = row - ROWS;
-                if (p0 + pr < p.P && k0 + c4 * 4 < p.Dp) v = *reinterpret_cast<const float4*>(p.protos + (size_t)(p0 + pr) * p.Dp + k0 + c4 * 4);
-                float* d = lpro + pr * LDP + c4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            stg[j] = v;
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256;
+            if (i < (ROWS + PB) * (BKF / 4)) {
+                const int row = i / (BKF / 4), c4 = i % (BKF / 4);
+                float* d = lds + row * LDP + c4 * 4;                 // ltok rows are followed by lpro rows at the same pitch
+                d[0] = stg[j].x; d[1] = stg[j].y; d[2] = stg[j].z; d[3] = stg[j].w;
             }
         }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < p.Dp; k0 += BKF) {
+        __syncthreads();                                             // everyone finished reading the previous chunk
+        sstore();
         __syncthreads();
+        if (k0 + BKF < p.Dp) gload(k0 + BKF);
 #pragma unroll
         for (int kk = 0; kk < BKF / 2; ++kk) {
             const float bv = lpro[(wave * 32 + (lane & 31)) * LDP + kk * 2 + hh];
