@@ -104,7 +104,7 @@ def main():
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from protopformer_amd import ops
+    from protopformer_amd import _lib, ops
     from protopformer_amd.engine import train_one_step
     model, opt, crit, sync = build(device, seed=1028)          # same seed on every rank, as the reference (main.py:254-255)
     g = torch.Generator(device=device).manual_seed(1028 + rank)
@@ -117,7 +117,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # roofline probe: HIP events around every launch of the dominant kernel (wgrad GEMM) on its launch stream
-    ops.PROFILE.update(enabled=True, key=ops.DOMINANT_KEY, events=[], flops=0.0, bytes=0.0)
+    _lib.call("ppf_gemm_probe", 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -129,16 +129,18 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.PROFILE["enabled"] = False
+    _lib.call("ppf_gemm_probe", 0)
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ops.PROFILE["events"])
-    n_launch = len(ops.PROFILE["events"])
+    import ctypes
+    c_ms, c_n, c_fl, c_by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+    _lib.call("ppf_gemm_probe_read", ctypes.addressof(c_ms), ctypes.addressof(c_n), ctypes.addressof(c_fl), ctypes.addressof(c_by))
+    kern_ms, n_launch, probe_flops, probe_bytes = c_ms.value, int(c_n.value), c_fl.value, c_by.value
     if rank == 0:
         ips = world * args.batch * args.steps / dt
-        achieved = (ops.PROFILE["flops"] / 1e12) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        achieved = (probe_flops / 1e12) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
         out = {
             "metric": "images/sec train step, deit_small+2000 protos, bs256, 1/2/4/8 MI355X", "value": ips, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps, "higher_is_better": True,
@@ -148,7 +150,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": ops.DOMINANT_NAME, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(), "traffic_unit": "bytes/launch (PMC, see profiles/r1_pmc_traffic.json)",
-                         "algorithmic_bytes": ops.PROFILE["bytes"] / max(n_launch, 1), "launches": n_launch,
+                         "algorithmic_bytes": probe_bytes / max(n_launch, 1), "launches": n_launch,
                          "avg_launch_ms": kern_ms / max(n_launch, 1)},
             "step_mfma_frac": (ips / world) * TRAIN_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
             "final_loss": float(loss),

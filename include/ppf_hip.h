@@ -51,6 +51,12 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
 /* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic two-pass reduction instead of atomics) */
 size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
+/* Roofline probe of the split-K weight-gradient kernel (epi 6 with a workspace): HIP events on the launch stream around the
+ * kernel itself.  ppf_gemm_probe(1) clears and starts, (0) stops; ppf_gemm_probe_read synchronises the events and returns the
+ * summed kernel time, the launch count and the algorithmic flops / bytes of those launches (bench.py's `roofline`). */
+int ppf_gemm_probe(int enable);
+int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, double* bytes);
+
 /* nbatch = batch_outer*batch_inner plain GEMMs; problem (o,i) uses A + o*sa_o + i*sa_i (elements), same for B / C.
  * kpad = 1: contraction-contiguous operands may read the (zero) padding up to the next multiple of 8 beyond K.
  * CaiT talking-heads attention per-(sample, head) products: A.V, dO.V^T, dS.K, dS^T.Q, A^T.dO (cait:128-130 and autograd). */

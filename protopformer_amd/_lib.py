@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
 SIGS = {
     "ppf_gemm_bf16": "pppiiiiiiiiippipipppipf" "pz" "s",
     "ppf_device_info": "pppi",
+    "ppf_gemm_probe": "i",
+    "ppf_gemm_probe_read": "pppp",
     "ppf_layernorm_fwd": "ppppppp" "iif" "s",
     "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "pz" "s",
     "ppf_layernorm_bwd_reduce": "p" "ii" "pppp" "s",

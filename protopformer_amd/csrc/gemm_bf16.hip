@@ -20,6 +20,8 @@
 #include "ppf_common.h"
 #include "gemm_common.h"
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 namespace {
 using namespace ppfg;
@@ -295,6 +297,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Launch probe (bench.py's roofline leg): HIP events on the launch stream around the split-K wgrad kernel itself -- not its
+// ordered reduce -- so that the live average agrees with rocprofv3's per-kernel average.
+struct Probe { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0.0, bytes = 0.0; };
+Probe g_probe;
+
 int pick_splitk(int M, int N, int K) {
     // wgrad-style problems (small output, very long contraction)
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -370,8 +377,16 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                 const size_t need = (size_t)ns * ((size_t)M * N + M) * sizeof(float);
                 if (workspace == nullptr || workspace_bytes < need || ns == 1) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
                 p.ws = (float*)workspace;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (g_probe.on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, stream); }
                 int rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
+                if (g_probe.on) {
+                    (void)hipEventRecord(e1, stream);
+                    g_probe.ev.emplace_back(e0, e1);
+                    g_probe.flops += 2.0 * M * N * (double)K;
+                    g_probe.bytes += 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N;
+                }
                 const size_t work = (size_t)M * N / 4 + (colsum ? M : 0);
                 const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns);
@@ -384,6 +399,32 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     }
     ppf_set_error("ppf_gemm_bf16: combination trans_a=%d trans_b=%d epi=%d not instantiated", trans_a, trans_b, epi);
     return PPF_ERR_ARG;
+}
+
+// Roofline probe of the weight-gradient kernel (epi 6 with a workspace).  enable = 1 clears and starts recording, 0 stops.
+int ppf_gemm_probe(int enable) {
+    if (enable) {
+        for (auto& e : g_probe.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        g_probe.ev.clear(); g_probe.flops = 0.0; g_probe.bytes = 0.0;
+    }
+    g_probe.on = enable != 0;
+    return 0;
+}
+// Synchronises the recorded events: total kernel milliseconds, launches, algorithmic flops and bytes since ppf_gemm_probe(1).
+int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, double* bytes) {
+    double ms = 0.0;
+    for (auto& e : g_probe.ev) {
+        float t = 0.f;
+        hipError_t rc = hipEventSynchronize(e.second);
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&t, e.first, e.second);
+        if (rc != hipSuccess) { ppf_set_error("ppf_gemm_probe_read: %s", hipGetErrorString(rc)); return (int)rc; }
+        ms += t;
+    }
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = (int64_t)g_probe.ev.size();
+    if (flops) *flops = g_probe.flops;
+    if (bytes) *bytes = g_probe.bytes;
+    return 0;
 }
 
 // Batched plain GEMMs (no bias / fused epilogue): nbatch = batch_outer * batch_inner problems, problem (o, i) uses

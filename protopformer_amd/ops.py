@@ -9,8 +9,6 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_SIGMOID_F32, EPI_RESID, EPI_DGELU, EPI_ATOMIC =
 
 
 # bench.py's roofline probe: HIP events (on the launch stream) around every launch of one GEMM instantiation
-PROFILE = dict(enabled=False, key=None, events=[], flops=0.0, bytes=0.0)
-DOMINANT_KEY = (True, True, EPI_ATOMIC)
 DOMINANT_NAME = "gemm_kernel<TA=1,TB=1,EPI_ATOMIC,COLSUM> (weight-gradient bf16 MFMA GEMM, split over the contraction)"
 
 
@@ -54,18 +52,9 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
     ws = None
     if epi == EPI_ATOMIC:
         ws = _workspace(a.device, _lib.lib().ppf_gemm_workspace_bytes(M, N, K))
-    probe = PROFILE["enabled"] and PROFILE["key"] == (bool(trans_a), bool(trans_b), epi)
-    if probe:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("ppf_gemm_bf16", a, b, out, M, N, K, a.shape[1], b.shape[1], out.shape[-1], int(trans_a), int(trans_b), epi,
               bias, res, res.shape[-1] if res is not None else 0, rowscale, rows_per_group, colscale, aux_in, aux_out, ldaux,
               colsum, float(alpha), ws, ws.numel() if ws is not None else 0)
-    if probe:
-        e1.record()
-        PROFILE["events"].append((e0, e1))
-        PROFILE["flops"] += 2.0 * M * N * K
-        PROFILE["bytes"] += 2.0 * (M * K + N * K) + out.element_size() * M * N      # operands read once + output written once
     return out
 
 
