@@ -85,9 +85,10 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
     } else if constexpr (EPI == EPI_F32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_GELU) {
-        float g[4], d[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gelu_erf_both(v[i], g[i], d[i]);
+        ppf_float2 g01, d01, g23, d23;
+        gelu_erf_both2(ppf_float2{v[0], v[1]}, g01, d01);
+        gelu_erf_both2(ppf_float2{v[2], v[3]}, g23, d23);
+        const float g[4] = {g01.x, g01.y, g23.x, g23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
         *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
     } else if constexpr (EPI == EPI_SIGMOID_F32) {

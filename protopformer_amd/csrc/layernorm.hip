@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
 
 // Bandwidth-oriented variant for D = 32*V*NJ (V = 4: D % 128 == 0, V = 2: D % 64 == 0): half a wavefront per row, so a
 // wave streams two independent rows at a time with 16-/8-byte accesses (twice the loads in flight of the generic kernel).
-template <int V, int NJ>
+// LS = false: no LayerScale operands (colscale / branch / dcolscale all null, the DeiT case): 24 fewer live registers -> 4 waves/SIMD.
+template <int V, int NJ, bool LS>
 __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
     __shared__ float red[WAVES][NJ * V * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
         for (int e = 0; e < V; ++e) {
             const int c = V * l32 + 32 * V * j + e;
             wv[j][e] = p.dy ? p.w[c] : 0.f;
-            cs[j][e] = p.colscale ? p.colscale[c] : 1.f;
+            cs[j][e] = (LS && p.colscale) ? p.colscale[c] : 1.f;
             adw[j][e] = adb[j][e] = anb[j][e] = acs[j][e] = 0.f;
         }
     const float invD = 1.0f / (float)D;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
                 float sx[V];
 #pragma unroll
                 for (int e = 0; e < V; ++e) sx[e] = dx[j][e] * rsc;
-                if (p.branch) {
+                if (LS && p.branch) {
                     float br[V];
                     if constexpr (V == 4) {
                         const uint2 u = *reinterpret_cast<const uint2*>(p.branch + src * D + c);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
                 uint32_t pk[V / 2];
 #pragma unroll
                 for (int e = 0; e < V; e += 2) {
-                    pk[e / 2] = pack_bf16x2(sx[e] * cs[j][e], sx[e + 1] * cs[j][e + 1]);
+                    pk[e / 2] = LS ? pack_bf16x2(sx[e] * cs[j][e], sx[e + 1] * cs[j][e + 1]) : pack_bf16x2(sx[e], sx[e + 1]);
                     const float2 rt = unpack_bf16x2(pk[e / 2]);
                     anb[j][e] += rt.x; anb[j][e + 1] += rt.y;
                 }
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
         }
     };
     if (p.dy) { flush(adw, p.dw, 0); flush(adb, p.db, 1); }
-    if (p.cast_out) { flush(anb, p.dbias_next, 2); if (p.branch) flush(acs, p.dcolscale, 3); }
+    if (p.cast_out) { flush(anb, p.dbias_next, 2); if (LS && p.branch) flush(acs, p.dcolscale, 3); }
 }
 
 // dst[c] += sum over workgroups of partial[wg][which][c], in a fixed order (deterministic; replaces ~1.8M fp32 atomics on 1152
@@ -374,7 +375,10 @@ int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const 
     PPF_CHECK_ARG(partial == nullptr || partial_bytes >= (size_t)(grid + LN_RS) * 4 * D * sizeof(float), PPF_ERR_ARG,
                   "ppf_layernorm_bwd: partial-sum workspace needs ppf_layernorm_bwd_blocks(rows)*4*D*4 = %zu bytes", (size_t)(grid + LN_RS) * 4 * D * sizeof(float));
     p.partial = partial;
-#define PPF_LN2(V, NJ) { hipLaunchKernelGGL((ln_bwd2_kernel<V, NJ>), dim3(grid), dim3(256), 0, stream, p); PPF_LAUNCH_CHECK(); return 0; }
+    const bool ls = colscale != nullptr || branch != nullptr || dcolscale != nullptr;
+#define PPF_LN2(V, NJ) { if (ls) hipLaunchKernelGGL((ln_bwd2_kernel<V, NJ, true>), dim3(grid), dim3(256), 0, stream, p); \
+                         else hipLaunchKernelGGL((ln_bwd2_kernel<V, NJ, false>), dim3(grid), dim3(256), 0, stream, p); \
+                         PPF_LAUNCH_CHECK(); return 0; }
     if (D % 128 == 0 && D <= 512) { switch (D / 128) { case 1: PPF_LN2(4, 1) case 2: PPF_LN2(4, 2) case 3: PPF_LN2(4, 3) case 4: PPF_LN2(4, 4) } }
     if (D % 64 == 0 && D <= 512) { switch (D / 64) { case 1: PPF_LN2(2, 1) case 3: PPF_LN2(2, 3) case 5: PPF_LN2(2, 5) case 7: PPF_LN2(2, 7) } }
 #undef PPF_LN2
