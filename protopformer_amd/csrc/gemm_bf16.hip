@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
             if (do_colsum && h == 0 && m < p.M) {
-                if constexpr (EPI == EPI_PARTIAL) p.ws[p.zslice * ((size_t)p.M * p.N + p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
+                if constexpr (EPI == EPI_PARTIAL) p.ws[p.zslice * ((size_t)p.M * p.N + (size_t)p.cs_parts * p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
                 else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
             }
         }
@@ -272,10 +272,10 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) 
     return tall ? launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch) : launch_impl<TA, TB, EPI, COLSUM, 2>(p, splitk, stream, nbatch);
 }
 
-// out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the M partial column sums
+// out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the cs_parts * M partial column sums
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, float* __restrict__ colsum,
-                                                            int M, int N, int ldc, int nsplit) {
-    const size_t mn = (size_t)M * N, slice = mn + (colsum ? M : 0);
+                                                            int M, int N, int ldc, int nsplit, int cs_parts) {
+    const size_t mn = (size_t)M * N, slice = mn + (colsum ? (size_t)cs_parts * M : 0);
     const size_t total4 = mn / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4 + (colsum ? M : 0); i += (size_t)gridDim.x * 256) {
         if (i < total4) {
@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         } else {
             const size_t m = i - total4;
             float acc = 0.f;
-            for (int z = 0; z < nsplit; ++z) acc += ws[z * slice + mn + m];
+            for (int z = 0; z < nsplit; ++z)
+                for (int q = 0; q < cs_parts; ++q) acc += ws[z * slice + mn + (size_t)q * M + m];
             colsum[m] += acc;
         }
     }
@@ -324,7 +325,9 @@ extern "C" {
 
 // Bytes of split-K workspace ppf_gemm_bf16 needs for an accumulating (epi = 6) problem of this shape.
 size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
-    return (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
+    const size_t a = (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
+    const size_t b = (size_t)nt256_wgrad_slices(M, N, K, 8, 8) * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);       // 256x256 path
+    return a > b ? a : b;
 }
 
 // Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
@@ -348,7 +351,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha; p.ws = nullptr;
-    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0;
+    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0; p.cs_parts = 1; p.nsplit = 1;
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
@@ -373,13 +376,17 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     } else {
         switch (epi) {
             case EPI_ATOMIC: {
-                const int ns = pick_splitk(M, N, K);
+                const int ns256 = workspace ? nt256_wgrad_slices(M, N, K, lda, ldb) : 0;
+                const bool big = ns256 > 0 && workspace_bytes >= (size_t)ns256 * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);
+                const int ns = big ? ns256 : pick_splitk(M, N, K);
                 const size_t need = (size_t)ns * ((size_t)M * N + M) * sizeof(float);
-                if (workspace == nullptr || workspace_bytes < need || ns == 1) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
+                if (!big && (workspace == nullptr || workspace_bytes < need || ns == 1)) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
                 p.ws = (float*)workspace;
+                p.cs_parts = big ? 4 : 1;
+                p.nsplit = ns;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (g_probe.on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, stream); }
-                int rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
+                int rc = big ? launch_nt256_wgrad(p, stream) : launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
                 if (g_probe.on) {
                     (void)hipEventRecord(e1, stream);
@@ -389,7 +396,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                 }
                 const size_t work = (size_t)M * N / 4 + (colsum ? M : 0);
                 const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns, p.cs_parts);
                 PPF_LAUNCH_CHECK();
                 return 0;
             }

@@ -26,6 +26,7 @@ struct GemmParams {
     long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
     int zslice;              // (device side) this workgroup's K slice
     int nsplit;              // split-K slices; grid.x = tiles * nsplit, slice-major so that an XCD owns whole K slices
+    int cs_parts;            // EPI_PARTIAL: partial column sums per slice and row (1: gemm_bf16.hip, 4: gemm_nt256.hip)
     int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
 };
 
@@ -74,7 +75,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
         return;
     }
     if constexpr (EPI == EPI_PARTIAL) {
-        const size_t slice = (size_t)p.M * p.N + (p.colsum ? p.M : 0);
+        const size_t slice = (size_t)p.M * p.N + (p.colsum ? (size_t)p.cs_parts * p.M : 0);
         *reinterpret_cast<float4*>(p.ws + p.zslice * slice + (size_t)m * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
         return;
     }
@@ -112,5 +113,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
 // 256x256x64 pipelined kernel for contraction-contiguous operands (gemm_nt256.hip)
 bool nt256_eligible(const GemmParams& p, int epi);
 int launch_nt256(const GemmParams& p, int epi, hipStream_t stream);
+int nt256_wgrad_slices(int M, int N, int K, int lda, int ldb);
+int launch_nt256_wgrad(const GemmParams& p, hipStream_t stream);
 
 }  // namespace ppfg

@@ -39,87 +39,151 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #define NT_BAR() __builtin_amdgcn_s_barrier()
 #define NT_PIN() __builtin_amdgcn_sched_barrier(0)
 
-struct Tile {                    // uniform description of one output tile
-    const unsigned char* a;      // A + m0s * lda (bytes): first row of the (shifted) tile
+struct Tile {                    // uniform description of one output tile (and, for split-K, of its slice of the contraction)
+    const unsigned char* a;      // first operand byte of the (shifted) tile at its first K tile
     const unsigned char* b;
     int m_lo, n_lo;              // outputs below these belong to the previous tile (edge tiles are shifted to stay in range)
     int m0s, n0s;                // shifted origin
+    int nt;                      // K tiles (even)
+    int z;                       // split-K slice
 };
 
 struct Ctx {
     Tile cur, nxt;
-    unsigned ta, tb;             // this thread's byte offset inside a 64-row x 64-k slab: (tid>>3) * ld * 2 + swizzled chunk * 16
-    unsigned sa, sb;             // 64 rows of A / B in bytes
+    unsigned ta, tb;             // this thread's byte offset inside one glds instruction's slab (swizzled source chunk)
+    unsigned ia, ib;             // second instruction of a half-tile: + 64 rows (NT) / + 32 contraction rows (TT)
+    unsigned ha, hb;             // second half-tile: + 128 rows (NT: 128*ld*2 bytes, TT: 256 bytes)
+    unsigned ka, kb;             // next K tile: + 128 bytes (NT) / + 64*ld*2 bytes (TT)
     unsigned char* smem;
     int wave_off;                // wave * 1024: this wave's 64 x 16 B run inside an 8 KiB instruction slab
-    int a_rd, b_rd;              // byte offsets of this wave's A / B fragment rows inside a K-tile buffer
-    int rd[4];                   // per-lane swizzled offset of k-substep ks
-    int nt;                      // K tiles per output tile (even)
+    int a_half, b_half;          // byte offsets of this wave's A / B half-tile inside a K-tile buffer
+    int b_row;                   // first B row (of 128) this wave multiplies
+    int rd[4];                   // NT: per-lane swizzled offset of k-substep ks.  TT: per-lane offset of 32-row sub-tile r5
+    int brd[2];                  // TT: the same for this wave's two B sub-tiles
     bool has_next;               // this workgroup has another output tile after the current one
+    bool colsum;                 // TT: accumulate sum_kc A(m, kc) for the current tile (bias gradient)
 };
 
 // Edge tiles are shifted back so that all 256 rows exist (M, N >= 256); the rows they share with the previous tile are
-// recomputed identically and masked out of the epilogue (m_lo / n_lo).
+// recomputed identically and masked out of the epilogue (m_lo / n_lo).  vid = slice * tiles + tile (n fastest).
+template <bool TT>
 __device__ __forceinline__ void tile_desc(const GemmParams& p, int vid, Tile& t) {
     const int tiles_n = (p.N + TN - 1) / TN;
-    t.m_lo = (vid / tiles_n) * TM; t.n_lo = (vid % tiles_n) * TN;
+    const int tiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int z = vid / tiles, v = vid - z * tiles;
+    t.z = z;
+    t.m_lo = (v / tiles_n) * TM; t.n_lo = (v % tiles_n) * TN;
     t.m0s = min(t.m_lo, p.M - TM); t.n0s = min(t.n_lo, p.N - TN);
-    t.a = reinterpret_cast<const unsigned char*>(p.A) + (size_t)t.m0s * p.lda * 2;
-    t.b = reinterpret_cast<const unsigned char*>(p.B) + (size_t)t.n0s * p.ldb * 2;
+    const int nkt = p.K / TK;
+    const int per = ((nkt + p.nsplit - 1) / p.nsplit + 1) & ~1;       // K tiles per slice, even
+    const int k0 = z * per;
+    t.nt = min(per, nkt - k0);
+    if (TT) {
+        t.a = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)k0 * TK * p.lda + t.m0s) * 2;
+        t.b = reinterpret_cast<const unsigned char*>(p.B) + ((size_t)k0 * TK * p.ldb + t.n0s) * 2;
+    } else {
+        t.a = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)t.m0s * p.lda + (size_t)k0 * TK) * 2;
+        t.b = reinterpret_cast<const unsigned char*>(p.B) + ((size_t)t.n0s * p.ldb + (size_t)k0 * TK) * 2;
+    }
 }
 
-// one half-tile (128 rows x 64 k): 1024 chunks of 16 B, two per thread (rows tid>>3 and 64 + tid>>3 of the half)
-__device__ __forceinline__ void stage_half(const Ctx& c, unsigned char* slot, const unsigned char* base, unsigned toff, unsigned s64, int half, int kt) {
-    const unsigned char* bk = base + (size_t)kt * (TK * 2) + (size_t)(2 * half) * s64;      // uniform
+// one half-tile (128 rows x 64 k): 1024 chunks of 16 B, two per thread
+__device__ __forceinline__ void stage_half(const Ctx& c, unsigned char* slot, const unsigned char* base, unsigned toff, unsigned istep,
+                                           unsigned hstep, unsigned kstep, int half, int kt) {
+    const unsigned char* bk = base + (size_t)kt * kstep + (size_t)half * hstep;      // uniform
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + (size_t)i * s64 + toff), (lds_void_t*)(slot + i * 8192 + c.wave_off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(bk + (size_t)i * istep + toff), (lds_void_t*)(slot + i * 8192 + c.wave_off), 16, 0, 0);
+}
+__device__ __forceinline__ void stage_a(const Ctx& c, unsigned char* slot, const Tile& t, int half, int kt) {
+    stage_half(c, slot, t.a, c.ta, c.ia, c.ha, c.ka, half, kt);
+}
+__device__ __forceinline__ void stage_b(const Ctx& c, unsigned char* slot, const Tile& t, int half, int kt) {
+    stage_half(c, slot, t.b, c.tb, c.ib, c.hb, c.kb, half, kt);
 }
 // K tile s of the stream that starts at the current output tile: s >= nt is K tile s - nt of the next output tile
 template <bool IS_A>
 __device__ __forceinline__ void stage_stream(const Ctx& c, unsigned char* slot, int half, int s) {
-    const Tile& t = s < c.nt ? c.cur : c.nxt;
-    const int kt = s < c.nt ? s : s - c.nt;
-    stage_half(c, slot, IS_A ? t.a : t.b, IS_A ? c.ta : c.tb, IS_A ? c.sa : c.sb, half, kt);
+    const Tile& t = s < c.cur.nt ? c.cur : c.nxt;
+    const int kt = s < c.cur.nt ? s : s - c.cur.nt;
+    if (IS_A) stage_a(c, slot, t, half, kt); else stage_b(c, slot, t, half, kt);
 }
 
-__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// MFMA fragment of the 32-row sub-tile at `row` (multiple of 32) of a half-tile, k-substep ks: lane l holds row l&31,
+// contraction values ks*16 + (l>>5)*8 .. +7.  NT half-tiles are [128 r][64 k] (b128 reads), TT half-tiles [64 k][128 r]
+// (two ds_read_b64_tr_b16, 64-byte units XOR-swizzled by k & 3: the layout of gemm_bf16.hip's transposed operands).
+template <bool TT>
+__device__ __forceinline__ bf16x8 lds_frag(const Ctx& c, const unsigned char* half, int row, int ks, int tt_off) {
+    if constexpr (!TT) {
+        return *reinterpret_cast<const bf16x8*>(half + row * 128 + c.rd[ks]);
+    } else {
+        // hipcc waits vmcnt(0) before a ds_read_tr builtin while LDS-DMA loads are in flight (it cannot tell the two apart), which
+        // would drain the prefetch ring every phase: issue the pair from inline asm and count lgkmcnt by hand (TT_LGKM_WAIT
+        // after the phase's first barrier).
+        // one address VGPR per 32-row sub-tile (uniform half-tile offset + per-lane part); the k-substep is an immediate offset
+        const unsigned addr = (unsigned)(size_t)(lds_void_t*)half + (unsigned)tt_off;
+        bf16x4 lo, hi;
+        switch (ks) {
+            case 0: asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory"); break;
+            case 1: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:4096\n\tds_read_b64_tr_b16 %1, %2 offset:5120" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory"); break;
+            case 2: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:8192\n\tds_read_b64_tr_b16 %1, %2 offset:9216" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory"); break;
+            default: asm volatile("ds_read_b64_tr_b16 %0, %2 offset:12288\n\tds_read_b64_tr_b16 %1, %2 offset:13312" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory"); break;
+        }
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+#define TT_LGKM_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// sum of the 8 bf16 values of a fragment (fp32)
+__device__ __forceinline__ float frag_sum(const bf16x8& f) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const u32x4 u = __builtin_bit_cast(u32x4, f);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += __uint_as_float(u[i] << 16) + __uint_as_float(u[i] & 0xffff0000u);
+    return s;
+}
 
 // Multiply K tile u (resident in buffer BI) up to the last MFMA of phase 4; the caller issues that phase's closing barrier.
 // TAIL = false: K tiles u+1 and u+2 are tiles of the current output tile (no tests in the loop body).
-template <int BI, bool TAIL>
-__device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4]) {
+template <int BI, bool TAIL, bool TT>
+__device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4], float (&csum)[4], int wc) {
     unsigned char* cur = c.smem + BI * BUFB;
     unsigned char* oth = c.smem + (BI ^ 1) * BUFB;
-    const unsigned char* ca = cur + c.a_rd;
-    const unsigned char* cb = cur + c.b_rd;
-    const bool more1 = !TAIL || (u + 1 < c.nt) || c.has_next;
-    const bool more2 = !TAIL || (u + 2 < c.nt) || c.has_next;
+    const unsigned char* ca = cur + c.a_half;
+    const unsigned char* cb = cur + c.b_half;
+    const bool more1 = !TAIL || (u + 1 < c.cur.nt) || c.has_next;
+    const bool more2 = !TAIL || (u + 2 < c.cur.nt) || c.has_next;
 
     // ---- phase 1: B sub-tiles 0/1 and A sub-tile 0 -> registers; quadrant (m 0-63, n 0-31)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        fb[0][ks] = lds_frag(cb + c.rd[ks]);
-        fb[1][ks] = lds_frag(cb + 32 * 128 + c.rd[ks]);
+        fb[0][ks] = lds_frag<TT>(c, cb, c.b_row, ks, c.brd[0]);
+        fb[1][ks] = lds_frag<TT>(c, cb, c.b_row + 32, ks, c.brd[1]);
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        fa[0][ks] = lds_frag(ca + c.rd[ks]);
-        fa[1][ks] = lds_frag(ca + 32 * 128 + c.rd[ks]);
+        fa[0][ks] = lds_frag<TT>(c, ca, 0, ks, c.rd[0]);
+        fa[1][ks] = lds_frag<TT>(c, ca, 32, ks, c.rd[1]);
     }
-    if (!TAIL) stage_half(c, oth + 0 * HALF, c.cur.a, c.ta, c.sa, 0, u + 1);
+    if (!TAIL) stage_a(c, oth + 0 * HALF, c.cur, 0, u + 1);
     else if (more1) stage_stream<true>(c, oth + 0 * HALF, 0, u + 1);
     NT_PIN(); NT_BAR(); NT_PIN();
+    if (TT) { TT_LGKM_WAIT(); NT_PIN(); }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][ks], fa[f][ks], acc[0][f], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    if (TT && c.colsum) {                        // bias gradient: wave wc owns k-substep wc of every A fragment row
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks == wc) { csum[0] += frag_sum(fa[0][ks]); csum[1] += frag_sum(fa[1][ks]); }
+    }
     NT_PIN(); NT_BAR(); NT_PIN();
 
     // ---- phase 2: quadrant (m 0-63, n 32-63)
-    if (!TAIL) stage_half(c, oth + 1 * HALF, c.cur.a, c.ta, c.sa, 1, u + 1);
+    if (!TAIL) stage_a(c, oth + 1 * HALF, c.cur, 1, u + 1);
     else if (more1) stage_stream<true>(c, oth + 1 * HALF, 1, u + 1);
     NT_PIN(); NT_BAR(); NT_PIN();
     __builtin_amdgcn_s_setprio(1);
@@ -134,24 +198,30 @@ __device__ __forceinline__ void ktile(const Ctx& c, int u, f32x16 (&acc)[2][4], 
     // phase 1: restage them with K tile u+2.
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        fa[0][ks] = lds_frag(ca + 64 * 128 + c.rd[ks]);
-        fa[1][ks] = lds_frag(ca + 96 * 128 + c.rd[ks]);
+        fa[0][ks] = lds_frag<TT>(c, ca, 64, ks, c.rd[2]);
+        fa[1][ks] = lds_frag<TT>(c, ca, 96, ks, c.rd[3]);
     }
-    if (!TAIL) stage_half(c, cur + 2 * HALF, c.cur.b, c.tb, c.sb, 0, u + 2);
+    if (!TAIL) stage_b(c, cur + 2 * HALF, c.cur, 0, u + 2);
     else if (more2) stage_stream<false>(c, cur + 2 * HALF, 0, u + 2);
     NT_PIN(); NT_BAR(); NT_PIN();
+    if (TT) { TT_LGKM_WAIT(); NT_PIN(); }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[1][2 + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][ks], fa[f][ks], acc[1][2 + f], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    if (TT && c.colsum) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks == wc) { csum[2] += frag_sum(fa[0][ks]); csum[3] += frag_sum(fa[1][ks]); }
+    }
     NT_PIN(); NT_BAR(); NT_PIN();
 
     // ---- phase 4: quadrant (m 64-127, n 0-31).  Retire K tile u+1 (everything but the two half-tiles of u+2 just issued)
     // BEFORE this phase's first barrier; it is read from the next phase on.
     if (!TAIL) {
-        stage_half(c, cur + 3 * HALF, c.cur.b, c.tb, c.sb, 1, u + 2);
+        stage_b(c, cur + 3 * HALF, c.cur, 1, u + 2);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else if (more2) {
         stage_stream<false>(c, cur + 3 * HALF, 1, u + 2);
@@ -215,7 +285,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, float* strip,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
-template <int EPI>
+template <int EPI, bool TT>
 __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -223,7 +293,8 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     const int wr = wave >> 2, wc = wave & 3;
 
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int ntiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int tiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int ntiles = tiles * p.nsplit;
     const int G = gridDim.x;
     // round j of the persistent loop covers tiles [j*G, (j+1)*G); inside a round consecutive tiles (n fastest: one A panel)
     // go to workgroups of the same XCD
@@ -233,19 +304,34 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     Ctx c;
     c.smem = smem;
     c.wave_off = wave * 1024;
-    c.nt = p.K / TK;
-    {
+    if constexpr (!TT) {
         const int r = tid >> 3, ch = (tid & 7) ^ ((r >> 1) & 7);      // rows r and 64 + r of a half share the swizzle
         c.ta = (unsigned)r * (unsigned)p.lda * 2u + ch * 16;
         c.tb = (unsigned)r * (unsigned)p.ldb * 2u + ch * 16;
-        c.sa = 64u * (unsigned)p.lda * 2u;
-        c.sb = 64u * (unsigned)p.ldb * 2u;
+        c.ia = 64u * (unsigned)p.lda * 2u; c.ib = 64u * (unsigned)p.ldb * 2u;
+        c.ha = 2u * c.ia; c.hb = 2u * c.ib;
+        c.ka = c.kb = TK * 2;
         const int l31 = lane & 31, hh = lane >> 5, sw = (l31 >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c.rd[ks] = l31 * 128 + (((ks * 2 + hh) ^ sw) << 4);
+    } else {
+        // half-tile image [64 kc][128 r]: chunk q = kc * 16 + c', position c' holds source chunk (((c'>>2) ^ (kc&3)) << 2) | (c'&3)
+        const int kc = tid >> 4, cp = tid & 15, ch = ((((cp >> 2) ^ (kc & 3))) << 2) | (cp & 3);
+        c.ta = (unsigned)kc * (unsigned)p.lda * 2u + ch * 16;
+        c.tb = (unsigned)kc * (unsigned)p.ldb * 2u + ch * 16;
+        c.ia = 32u * (unsigned)p.lda * 2u; c.ib = 32u * (unsigned)p.ldb * 2u;
+        c.ha = c.hb = 256;
+        c.ka = 64u * (unsigned)p.lda * 2u; c.kb = 64u * (unsigned)p.ldb * 2u;
+        const int s16 = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
+#pragma unroll
+        for (int r5 = 0; r5 < 4; ++r5)           // sub-tile r5 of a half: lane part + the swizzled 64-byte unit
+            c.rd[r5] = (8 * hh + (s16 >> 2)) * 256 + ((16 * g16 + 4 * (s16 & 3)) << 1) + ((r5 ^ ((s16 >> 2) & 3)) << 6);
     }
-    c.a_rd = wr * HALF;
-    c.b_rd = (2 + (wc >> 1)) * HALF + (wc & 1) * 64 * 128;
+    c.a_half = wr * HALF;
+    c.b_half = (2 + (wc >> 1)) * HALF;
+    c.b_row = (wc & 1) * 64;
+    c.brd[0] = (wc & 1) ? c.rd[2] : c.rd[0];
+    c.brd[1] = (wc & 1) ? c.rd[3] : c.rd[1];
     float* strip = reinterpret_cast<float*>(smem + RING + wave * STRIP);
 
     f32x16 acc[2][4];
@@ -256,16 +342,17 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 fa[2][4], fb[2][4];
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // prologue: K tile 0 of the first output tile complete, the B half-tiles of K tile 1 in flight
-    tile_desc(p, vid, c.cur);
+    tile_desc<TT>(p, vid, c.cur);
     c.nxt = c.cur;
-    stage_half(c, smem + 2 * HALF, c.cur.b, c.tb, c.sb, 0, 0);
-    stage_half(c, smem + 3 * HALF, c.cur.b, c.tb, c.sb, 1, 0);
-    stage_half(c, smem + 0 * HALF, c.cur.a, c.ta, c.sa, 0, 0);
-    stage_half(c, smem + 1 * HALF, c.cur.a, c.ta, c.sa, 1, 0);
-    stage_half(c, smem + BUFB + 2 * HALF, c.cur.b, c.tb, c.sb, 0, 1);
-    stage_half(c, smem + BUFB + 3 * HALF, c.cur.b, c.tb, c.sb, 1, 1);
+    stage_b(c, smem + 2 * HALF, c.cur, 0, 0);
+    stage_b(c, smem + 3 * HALF, c.cur, 1, 0);
+    stage_a(c, smem + 0 * HALF, c.cur, 0, 0);
+    stage_a(c, smem + 1 * HALF, c.cur, 1, 0);
+    stage_b(c, smem + BUFB + 2 * HALF, c.cur, 0, 1);
+    stage_b(c, smem + BUFB + 3 * HALF, c.cur, 1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     NT_PIN(); NT_BAR(); NT_PIN();
     if (wr == 1) { NT_BAR(); }                   // the second m-half runs one barrier behind the first
@@ -274,22 +361,41 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     for (;;) {
         const int nvid = vid + G;
         c.has_next = nvid < ntiles;
-        if (c.has_next) tile_desc(p, nvid, c.nxt);
+        if (c.has_next) tile_desc<TT>(p, nvid, c.nxt);
+        c.colsum = TT && EPI == EPI_PARTIAL && p.colsum != nullptr && c.cur.n_lo == 0;
         int u = 0;
-        for (; u + 3 < c.nt; u += 2) {
-            ktile<0, false>(c, u, acc, fa, fb);
+        for (; u + 3 < c.cur.nt; u += 2) {
+            ktile<0, false, TT>(c, u, acc, fa, fb, csum, wc);
             NT_BAR(); NT_PIN();
-            ktile<1, false>(c, u + 1, acc, fa, fb);
+            ktile<1, false, TT>(c, u + 1, acc, fa, fb, csum, wc);
             NT_BAR(); NT_PIN();
         }
-        ktile<0, true>(c, u, acc, fa, fb);
+        ktile<0, true, TT>(c, u, acc, fa, fb, csum, wc);
         NT_BAR(); NT_PIN();
-        ktile<1, true>(c, u + 1, acc, fa, fb);
+        ktile<1, true, TT>(c, u + 1, acc, fa, fb, csum, wc);
         // tile boundary: both m-halves run their epilogue in the barrier interval that follows the first half's last MFMA
         const int m0 = c.cur.m0s + wr * 128, n0 = c.cur.n0s + wc * 64;
-        if (wr == 1) tile_epilogue<EPI>(p, strip, m0, n0, c.cur.m_lo, c.cur.n_lo, lane, acc);
+        GemmParams q = p;
+        q.zslice = c.cur.z;
+        auto finish = [&]() {
+            tile_epilogue<EPI>(q, strip, m0, n0, c.cur.m_lo, c.cur.n_lo, lane, acc);
+            if constexpr (TT && EPI == EPI_PARTIAL) {
+                if (c.colsum) {                  // 4 partial column sums per row (one per k-substep owner), added up by the reduce kernel
+                    const size_t slice = (size_t)p.M * p.N + (size_t)p.cs_parts * p.M;
+                    float* dst = p.ws + c.cur.z * slice + (size_t)p.M * p.N + (size_t)wc * p.M;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const float v = csum[mi] + __shfl_xor(csum[mi], 32, 64);
+                        const int m = m0 + 32 * mi + (lane & 31);
+                        if (lane < 32 && m >= c.cur.m_lo) dst[m] = v;
+                        csum[mi] = 0.f;
+                    }
+                }
+            }
+        };
+        if (wr == 1) finish();
         NT_PIN(); NT_BAR(); NT_PIN();
-        if (wr == 0) tile_epilogue<EPI>(p, strip, m0, n0, c.cur.m_lo, c.cur.n_lo, lane, acc);
+        if (wr == 0) finish();
         NT_PIN();
         if (!c.has_next) break;
         vid = nvid;
@@ -298,17 +404,22 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     if (wr == 0) { NT_BAR(); }                   // every wave executes the same number of barriers
 }
 
-template <int EPI>
+int num_cus() {
+    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    return ncu;
+}
+
+template <int EPI, bool TT>
 int launch_one(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm_nt256_kernel<EPI>;
+    auto kern = gemm_nt256_kernel<EPI, TT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm_nt256): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN);
-    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN) * p.nsplit;
+    const int ncu = num_cus();
     hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(NTHR), LDS_BYTES, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;
@@ -334,17 +445,40 @@ bool nt256_eligible(const GemmParams& p, int epi) {
     return tiles >= 192 && p.K >= 768 && (long long)tn * TN * 10 <= (long long)p.N * 11;
 }
 
-int launch_nt256(const GemmParams& p, int epi, hipStream_t stream) {
+int launch_nt256(const GemmParams& p_, int epi, hipStream_t stream) {
+    GemmParams p = p_;
+    p.nsplit = 1;
     switch (epi) {
-        case EPI_BF16: return launch_one<EPI_BF16>(p, stream);
-        case EPI_F32: return launch_one<EPI_F32>(p, stream);
-        case EPI_GELU: return launch_one<EPI_GELU>(p, stream);
-        case EPI_RESID: return launch_one<EPI_RESID>(p, stream);
-        case EPI_DGELU: return launch_one<EPI_DGELU>(p, stream);
+        case EPI_BF16: return launch_one<EPI_BF16, false>(p, stream);
+        case EPI_F32: return launch_one<EPI_F32, false>(p, stream);
+        case EPI_GELU: return launch_one<EPI_GELU, false>(p, stream);
+        case EPI_RESID: return launch_one<EPI_RESID, false>(p, stream);
+        case EPI_DGELU: return launch_one<EPI_DGELU, false>(p, stream);
         default: break;
     }
     ppf_set_error("gemm_nt256: epilogue %d not instantiated", epi);
     return PPF_ERR_ARG;
 }
+
+// Weight-gradient problems (both operands contraction-strided, fp32 split-K partials): one (tile, K slice) per CU.
+// Returns the slice count, or 0 when the shape does not qualify (the 128x128 kernel takes it).
+int nt256_wgrad_slices(int M, int N, int K, int lda, int ldb) {
+    // Measured (scripts/gpu/wgrad_check.py, profiles/r1_gemm_nt256.txt): correct and deterministic, but 5-20 % SLOWER than the
+    // 128x128 kernel on the train step's weight gradients -- both operands stream from HBM (~2 us latency) and the two-K-tile
+    // ring keeps only ~48 KiB per CU in flight (vs 3 x 32 KiB for three 128x128 workgroups).  Opt-in until the ring is deeper.
+    static const int mode = getenv("PPF_GEMM_NT256_WGRAD") ? atoi(getenv("PPF_GEMM_NT256_WGRAD")) : 0;
+    if (!mode || M < TM || N < TN || K % (2 * TK) != 0 || K < 32 * TK) return 0;
+    if ((long long)lda * 64 >= (1ll << 30) || (long long)ldb * 64 >= (1ll << 30) || (lda % 8) || (ldb % 8) || (M % 8) || (N % 8)) return 0;
+    const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    const int nkt = K / TK;
+    int s = num_cus() / tiles;
+    if (s < 1) s = 1;
+    if (s > nkt / 8) s = nkt / 8;                        // >= 8 K tiles per slice
+    if (s < 1) return 0;
+    const int per = ((nkt + s - 1) / s + 1) & ~1;        // even K tiles per slice; drop the slices that would be empty
+    return (nkt + per - 1) / per;
+}
+
+int launch_nt256_wgrad(const GemmParams& p, hipStream_t stream) { return launch_one<EPI_PARTIAL, true>(p, stream); }
 
 }  // namespace ppfg

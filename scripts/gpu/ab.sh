@@ -1,3 +1,2 @@
-for i in 1 2 3; do
-timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c90-200
-done
+echo "--- nt256 wgrad"; timeout 300 python scripts/gpu/wgrad_check.py 2>&1 | tail -7
+echo "--- 128x128"; PPF_GEMM_NT256_WGRAD=0 timeout 300 python scripts/gpu/wgrad_check.py 2>&1 | tail -7
