@@ -214,6 +214,9 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
                     make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // cross-lane exchange through the wave's private strip:
+        __builtin_amdgcn_wave_barrier();                           // keep the compiler from moving reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int col = (lane & 15) * 4;
         const int n = n0 + wn + col;
         const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
@@ -230,6 +233,9 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
             const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
             if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // the next 32-row block overwrites the strip
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
             if (do_colsum && h == 0 && m < p.M) {
@@ -326,8 +332,9 @@ extern "C" {
 // Bytes of split-K workspace ppf_gemm_bf16 needs for an accumulating (epi = 6) problem of this shape.
 size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
     const size_t a = (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
-    const size_t b = (size_t)nt256_wgrad_slices(M, N, K, 8, 8) * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);       // 256x256 path
-    return a > b ? a : b;
+    const size_t b = (size_t)nt256_wgrad_slices(M, N, K, 8, 8) * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);       // 256x256 paths
+    const size_t c = (size_t)tt_deep_slices(M, N, K, 8, 8) * ((size_t)M * N + M) * sizeof(float);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 // Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
@@ -376,17 +383,21 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     } else {
         switch (epi) {
             case EPI_ATOMIC: {
-                const int ns256 = workspace ? nt256_wgrad_slices(M, N, K, lda, ldb) : 0;
+                // three kernels can take a weight gradient: the deep-ring 256x256 kernel (default where eligible), the two-K-tile
+                // 256x256 kernel (opt-in) and the 128x128 kernel
+                const int nsd = workspace ? tt_deep_slices(M, N, K, lda, ldb) : 0;
+                const bool deep = nsd > 0 && workspace_bytes >= (size_t)nsd * ((size_t)M * N + M) * sizeof(float);
+                const int ns256 = (!deep && workspace) ? nt256_wgrad_slices(M, N, K, lda, ldb) : 0;
                 const bool big = ns256 > 0 && workspace_bytes >= (size_t)ns256 * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);
-                const int ns = big ? ns256 : pick_splitk(M, N, K);
+                const int ns = deep ? nsd : big ? ns256 : pick_splitk(M, N, K);
                 const size_t need = (size_t)ns * ((size_t)M * N + M) * sizeof(float);
-                if (!big && (workspace == nullptr || workspace_bytes < need || ns == 1)) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
+                if (!deep && !big && (workspace == nullptr || workspace_bytes < need || ns == 1)) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
                 p.ws = (float*)workspace;
                 p.cs_parts = big ? 4 : 1;
                 p.nsplit = ns;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (g_probe.on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, stream); }
-                int rc = big ? launch_nt256_wgrad(p, stream) : launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
+                int rc = deep ? launch_tt_deep(p, stream) : big ? launch_nt256_wgrad(p, stream) : launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
                 if (g_probe.on) {
                     (void)hipEventRecord(e1, stream);

@@ -115,5 +115,7 @@ bool nt256_eligible(const GemmParams& p, int epi);
 int launch_nt256(const GemmParams& p, int epi, hipStream_t stream);
 int nt256_wgrad_slices(int M, int N, int K, int lda, int ldb);
 int launch_nt256_wgrad(const GemmParams& p, hipStream_t stream);
+int tt_deep_slices(int M, int N, int K, int lda, int ldb);
+int launch_tt_deep(const GemmParams& p, hipStream_t stream);
 
 }  // namespace ppfg

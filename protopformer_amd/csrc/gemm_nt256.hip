@@ -262,6 +262,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, float* strip,
                             make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
                     }
             }
+            // lanes exchange data through the strip without a workgroup barrier: the LDS unit keeps one wave's accesses in order,
+            // but the compiler must not move a lane's reads above other lanes' (divergent) writes -> wave-level fences
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             EpiRow rr[4];
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -275,6 +280,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, float* strip,
                 const float4 v = *reinterpret_cast<const float4*>(strip + r * 64 + (((lane & 15) ^ r) << 2));
                 if (m >= m_lo && n >= n_lo) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                 // the next unit overwrites the strip
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 #pragma unroll
@@ -404,6 +412,154 @@ __global__ __launch_bounds__(NTHR) void gemm_nt256_kernel(const GemmParams p) {
     if (wr == 0) { NT_BAR(); }                   // every wave executes the same number of barriers
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight-gradient kernel with a deep ring: C[m][n] = sum_kc A[kc*lda + m] * B[kc*ldb + n] over one slice of a very long
+// contraction, both operands streamed from HBM.  What bounds this is bytes in flight per CU (latency ~2 us): five 32 KiB stages
+// of [32 kc][256 m] + [32 kc][256 n] fill the whole 160 KiB of LDS, three of them in flight (96 KiB) while one is multiplied.
+// 256x256 outputs per workgroup (half the operand bytes per flop of the 128x128 kernel), 8 waves of 128x64, fragments by
+// ds_read_b64_tr_b16 from inline asm, two barriers per stage with the two m-halves one barrier apart (one reads fragments and
+// issues loads while the other multiplies).  A stage slot is refilled two phases after its last read, the stage read next is
+// retired by a counted vmcnt one phase ahead.
+constexpr int DK = 32, DNS = 5;
+constexpr int DOPER = DK * 256 * 2;          // 16 KiB: one operand of one stage
+constexpr int DSLOT = 2 * DOPER;
+constexpr int DLDS = DNS * DSLOT;            // 160 KiB
+
+struct DCtx {
+    const unsigned char* a; const unsigned char* b;
+    unsigned ta, tb, ia, ib, ka, kb;
+    unsigned char* smem;
+    int wave_off;
+    int ard[4], brd[2];                      // per-lane fragment offsets of this wave's 4 A / 2 B 32-row sub-tiles
+};
+
+__device__ __forceinline__ void dstage(const DCtx& c, int slot, int kt) {
+    unsigned char* s = c.smem + slot * DSLOT + c.wave_off;
+    const unsigned char* ba = c.a + (size_t)kt * c.ka;
+    const unsigned char* bb = c.b + (size_t)kt * c.kb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(ba + (size_t)i * c.ia + c.ta), (lds_void_t*)(s + i * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(bb + (size_t)i * c.ib + c.tb), (lds_void_t*)(s + DOPER + i * 8192), 16, 0, 0);
+    }
+}
+template <int KS>
+__device__ __forceinline__ bf16x8 dfrag(unsigned addr) {
+    bf16x4 lo, hi;
+    if constexpr (KS == 0) asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+    else asm volatile("ds_read_b64_tr_b16 %0, %2 offset:8192\n\tds_read_b64_tr_b16 %1, %2 offset:10240" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(NTHR) void gemm_tt_deep_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int tiles = tiles_n * ((p.M + TM - 1) / TM);
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = vid / tiles, v = vid - z * tiles;
+    const int m_lo = (v / tiles_n) * TM, n_lo = (v % tiles_n) * TN;
+    const int m0s = min(m_lo, p.M - TM), n0s = min(n_lo, p.N - TN);
+    const int nkt = p.K / DK, per = (nkt + p.nsplit - 1) / p.nsplit, k0 = z * per;
+    const int nt = min(per, nkt - k0);
+    if (nt <= 0) return;
+
+    DCtx c;
+    c.smem = smem;
+    c.wave_off = wave * 1024;
+    c.a = reinterpret_cast<const unsigned char*>(p.A) + ((size_t)k0 * DK * p.lda + m0s) * 2;
+    c.b = reinterpret_cast<const unsigned char*>(p.B) + ((size_t)k0 * DK * p.ldb + n0s) * 2;
+    {
+        // operand image [32 kc][256 r] (512-byte rows): chunk q = kc * 32 + c', position c' holds source chunk
+        // (((c'>>2) ^ (kc&3)) << 2) | (c'&3) -- the 64-byte-unit swizzle the transposed reads expect
+        const int kc = tid >> 5, cp = tid & 31, ch = ((((cp >> 2) ^ (kc & 3))) << 2) | (cp & 3);
+        c.ta = (unsigned)kc * (unsigned)p.lda * 2u + ch * 16;
+        c.tb = (unsigned)kc * (unsigned)p.ldb * 2u + ch * 16;
+        c.ia = 16u * (unsigned)p.lda * 2u; c.ib = 16u * (unsigned)p.ldb * 2u;
+        c.ka = (unsigned)DK * (unsigned)p.lda * 2u; c.kb = (unsigned)DK * (unsigned)p.ldb * 2u;
+        const int s16 = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5, kq = (s16 >> 2) & 3;
+        const int lp = (8 * hh + (s16 >> 2)) * 512 + ((16 * g16 + 4 * (s16 & 3)) << 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c.ard[i] = lp + (((wr * 4 + i) ^ kq) << 6);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c.brd[i] = DOPER + lp + (((wc * 2 + i) ^ kq) << 6);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
+    const bool colsum = p.colsum != nullptr && n_lo == 0;
+
+    // prologue: stages 0..2 in flight, stage 0 landed
+    dstage(c, 0, 0);
+    if (nt > 1) dstage(c, 1, 1);
+    if (nt > 2) dstage(c, 2, 2);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_PIN(); NT_BAR(); NT_PIN();
+    if (wr == 1) { NT_BAR(); }
+    NT_PIN();
+
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+    int slot = 0;
+    for (int u = 0; u < nt; ++u) {
+        const unsigned sb = lds0 + slot * DSLOT;
+        bf16x8 fa[4][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { fb[i][0] = dfrag<0>(sb + c.brd[i]); fb[i][1] = dfrag<1>(sb + c.brd[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i][0] = dfrag<0>(sb + c.ard[i]); fa[i][1] = dfrag<1>(sb + c.ard[i]); }
+        const int rem = nt - 1 - u;              // stages after this one
+        if (rem >= 3) {
+            int s3 = slot + 3; if (s3 >= DNS) s3 -= DNS;
+            dstage(c, s3, u + 3);                // slot last read two phases ago
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (rem == 2) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (rem == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        NT_PIN(); NT_BAR(); NT_PIN();
+        TT_LGKM_WAIT(); NT_PIN();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni][ks], fa[mi][ks], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (colsum) {                            // bias gradient: wave wc owns rows 32*wc.. of its m-half
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                if (mi == wc) csum += frag_sum(fa[mi][0]) + frag_sum(fa[mi][1]);
+        }
+        NT_PIN(); NT_BAR(); NT_PIN();
+        if (++slot == DNS) slot = 0;
+    }
+    if (wr == 0) { NT_BAR(); }                   // re-align the halves: every fragment read has retired, nothing is in flight
+    NT_PIN();
+
+    GemmParams q = p;
+    q.zslice = z;
+    float* strip = reinterpret_cast<float*>(smem + wave * STRIP);
+    const int m0 = m0s + wr * 128, n0 = n0s + wc * 64;
+    tile_epilogue<EPI_PARTIAL>(q, strip, m0, n0, m_lo, n_lo, lane, acc);
+    if (colsum) {
+        const size_t slice = (size_t)p.M * p.N + (size_t)p.cs_parts * p.M;
+        const float vsum = csum + __shfl_xor(csum, 32, 64);
+        const int m = m0 + 32 * wc + (lane & 31);
+        if (lane < 32 && m >= m_lo) p.ws[z * slice + (size_t)p.M * p.N + m] = vsum;
+    }
+}
+
 int num_cus() {
     static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     return ncu;
@@ -480,5 +636,36 @@ int nt256_wgrad_slices(int M, int N, int K, int lda, int ldb) {
 }
 
 int launch_nt256_wgrad(const GemmParams& p, hipStream_t stream) { return launch_one<EPI_PARTIAL, true>(p, stream); }
+
+// Deep-ring weight-gradient kernel (gemm_tt_deep_kernel): slices so that (tiles x slices) fills the CUs once; 0 = not eligible.
+int tt_deep_slices(int M, int N, int K, int lda, int ldb) {
+    // Measured (profiles/r1_gemm_nt256.txt): alone on the GPU -13 % on the fc1 / fc2 weight gradients (95 vs 109 us), equal on
+    // qkv, slower on proj; inside the train step, where these GEMMs share the GPU with the dgrad chain, a workgroup that owns a
+    // whole CU's LDS costs the main stream more than it saves (12.93k vs 13.02k img/s) -> opt-in (1; 2 also takes small outputs).
+    static const int mode = getenv("PPF_GEMM_TT_DEEP") ? atoi(getenv("PPF_GEMM_TT_DEEP")) : 0;
+    if (!mode || M < TM || N < TN || K % DK != 0 || K < 64 * DK) return 0;
+    if ((long long)lda * 32 >= (1ll << 30) || (long long)ldb * 32 >= (1ll << 30) || (lda % 8) || (ldb % 8) || (M % 8) || (N % 8)) return 0;
+    const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    if (tiles < 8 && mode != 2) return 0;                // few output tiles = many short slices: the 128x128 kernel is faster (measured)
+    const int nkt = K / DK;
+    int s = num_cus() / tiles;
+    if (s > nkt / 16) s = nkt / 16;                      // >= 16 stages per slice
+    if (s < 1) return 0;
+    const int per = (nkt + s - 1) / s;
+    return (nkt + per - 1) / per;                        // no empty slices
+}
+
+int launch_tt_deep(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tt_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm_tt_deep): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN) * p.nsplit;
+    hipLaunchKernelGGL(gemm_tt_deep_kernel, dim3(tiles), dim3(NTHR), DLDS, stream, p);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
 
 }  // namespace ppfg
