@@ -17,6 +17,10 @@ import os
 import sys
 import time
 
+# ROCm maps HIP streams round-robin onto GPU_MAX_HW_QUEUES (default 4) hardware queues; with the RCCL / comm streams of a
+# multi-GPU run the weight-gradient lane could land on the main stream's queue and serialise with it.  Must be set before HIP loads.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 import torch.distributed as dist
 
@@ -40,7 +44,7 @@ def build(device, seed):
     model = model.to(device)
     model.train()
     opt = FlatAdamW(model, weight_decay=0.05, ema_decay=0.99996)
-    sync = make_grad_sync(model) if dist.is_initialized() and dist.get_world_size() > 1 else None
+    sync = make_grad_sync(model) if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0") else None
     return model, opt, CrossEntropyLoss(), sync
 
 
@@ -99,8 +103,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 

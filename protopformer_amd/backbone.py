@@ -199,8 +199,7 @@ def deit_backward(ppnet, store, saved, df):
                       rows_per_group=N, dbias_next=store.grad_view(last.mlp.fc2.bias))
     gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
     if gs is not None:
-        lane.join()
-        gs.chunk_ready(gs.tail_chunk)
+        gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
     for i in range(len(layers) - 1, -1, -1):
         L, blk = layers[i], feats.blocks[i]
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
@@ -228,16 +227,15 @@ def deit_backward(ppnet, store, saved, df):
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
-            lane.join()
-            gs.chunk_ready(gs.block_chunk[i])
+            gs.chunk_ready(gs.block_chunk[i], also=(lane.stream,))
     # token assembly + patch embedding
     pe = feats.patch_embed
     Np = pe.num_patches
     dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(N, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
-    lane.join()
     if gs is not None:
-        gs.chunk_ready(gs.head_chunk)
+        gs.chunk_ready(gs.head_chunk, also=(lane.stream,))
+    lane.join()
 
 
 class TokensFn(torch.autograd.Function):

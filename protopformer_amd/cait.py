@@ -299,15 +299,14 @@ def cait_backward(ppnet, store, saved, df):
         else:
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
-            lane.join()
-            gs.chunk_ready(gs.block_chunk[i])
+            gs.chunk_ready(gs.block_chunk[i], also=(lane.stream,))
     pe = feats.patch_embed
     dtok = ops.assemble_tokens_bwd(dx, gv(feats.pos_embed).reshape(N, D), None, B, N, D, 0)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
-    lane.join()
     if gs is not None:
-        gs.chunk_ready(gs.head_chunk)
-        gs.chunk_ready(gs.tail_chunk)
+        gs.chunk_ready(gs.head_chunk, also=(lane.stream,))
+        gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
+    lane.join()
 
 
 CAIT_FNS = dict(embed=cait_embed, blocks=cait_blocks_fwd, backward=cait_backward)

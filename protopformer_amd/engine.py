@@ -8,6 +8,7 @@
 * train_one_step / train_one_epoch : the reference's step body (forward, CE + PPC, backward, step, EMA).
 """
 import math
+import os
 import sys
 
 import torch
@@ -81,25 +82,35 @@ class GradSync:
         self.g = flat_grads
         self.bounds = list(chunk_bounds)                      # ascending element offsets; chunk c = [bounds[c], bounds[c+1])
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.force = os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0"     # single-rank runs still issue the collectives (tests)
         self.cuda = flat_grads.is_cuda
         self.stream = torch.cuda.Stream() if (self.cuda and use_side_stream) else None
         self.pending = []
 
-    def chunk_ready(self, c):
-        """Launch the all-reduce of chunk c: every kernel that writes it has been enqueued on the current stream."""
-        if self.world == 1:
+    def chunk_ready(self, c, also=()):
+        """Launch the all-reduce of chunk c: every kernel that writes it has been enqueued on the current stream or on one of
+        the `also` streams (the weight-gradient lane) -- the communication stream waits for all of them, the compute streams
+        never wait for each other here."""
+        if self.world == 1 and not self.force:
             return
         lo, hi = self.bounds[c], self.bounds[c + 1]
         if hi <= lo:
             return
         view = self.g[lo:hi]
         if self.stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            evs = []
+            for st in (torch.cuda.current_stream(),) + tuple(s_ for s_ in also if s_ is not None):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
             with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ev)
+                for ev in evs:
+                    self.stream.wait_event(ev)
                 self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
+            for st in also:
+                if st is not None:
+                    torch.cuda.current_stream().wait_stream(st)
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):

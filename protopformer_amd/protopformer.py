@@ -243,6 +243,7 @@ class PPNet(nn.Module):
                       ("prototype_vectors", [("prototype_vectors", self.prototype_vectors)]),
                       ("prototype_vectors_global", [("prototype_vectors_global", self.prototype_vectors_global)])]
             self._flat = FlatStore(self, groups)
+            wgrad_lane(self._flat)             # create the side stream now, before any communication stream claims a hardware queue
         return self._flat
 
     def _hook_params(self):

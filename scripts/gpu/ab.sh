@@ -1,5 +1,2 @@
-timeout 800 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "^E |passed|failed|Error|error|^tests" | cut -c1-300
-for i in 1 2; do
-timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c90-200
-PPF_GEMM_TT_DEEP=0 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c90-200
-done
+PPF_FORCE_GRADSYNC=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -3 | cut -c1-300
+timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
