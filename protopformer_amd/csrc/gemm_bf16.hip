@@ -214,9 +214,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
                     make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // cross-lane exchange through the wave's private strip:
         __builtin_amdgcn_wave_barrier();                           // keep the compiler from moving reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int col = (lane & 15) * 4;
         const int n = n0 + wn + col;
         const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
@@ -233,9 +231,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
             const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
             if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                           // the next 32-row block overwrites the strip
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
             if (do_colsum && h == 0 && m < p.M) {

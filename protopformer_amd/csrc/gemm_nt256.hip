@@ -263,10 +263,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, float* strip,
                     }
             }
             // lanes exchange data through the strip without a workgroup barrier: the LDS unit keeps one wave's accesses in order,
-            // but the compiler must not move a lane's reads above other lanes' (divergent) writes -> wave-level fences
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // but the compiler must not move a lane's reads above other lanes' (divergent) writes -> wave_barrier (no instruction;
+            // a release/acquire fence pair also works but makes hipcc wait vmcnt(0), i.e. for the previous unit's global stores)
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             EpiRow rr[4];
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -280,9 +279,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, float* strip,
                 const float4 v = *reinterpret_cast<const float4*>(strip + r * 64 + (((lane & 15) ^ r) << 2));
                 if (m >= m_lo && n >= n_lo) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                 // the next unit overwrites the strip
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 #pragma unroll

@@ -1,2 +1,5 @@
-PPF_FORCE_GRADSYNC=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -3 | cut -c1-300
-timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+PPF_GEMM_TT_DEEP=1 timeout 300 python scripts/gpu/wgrad_dbg.py 2>&1 | tail -1 | cut -c1-100
+PPF_GEMM_TT_DEEP=1 timeout 300 python scripts/gpu/wgrad_check.py 2>&1 | tail -1
+PPF_GEMM_NT256=1 timeout 300 python scripts/gpu/gemm_check.py 2>&1 | tail -2
+echo "--- nt256"; PPF_GEMM_NT256=1 timeout 300 python scripts/gpu/gemm_big.py 2>&1 | tail -3 | head -2
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c90-200
