@@ -8,7 +8,9 @@ from oracle import ppf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("rows,D", [(394, 384), (1000, 192), (77, 96), (50, 128), (33, 64)])
+# rows >= 4096 take the partial-sum + ordered-reduce path for the column sums (and, without LayerScale operands, the
+# specialised kernel); smaller calls use fp32 atomics
+@pytest.mark.parametrize("rows,D", [(394, 384), (1000, 192), (77, 96), (50, 128), (33, 64), (6304, 384), (4100, 192)])
 def test_layernorm_fwd_bwd(rows, D):
     from protopformer_amd import ops
     g = torch.Generator().manual_seed(0)
@@ -42,6 +44,33 @@ def test_layernorm_fwd_bwd(rows, D):
     assert_close(cast.float(), cast_ref, rtol=8e-3, atol=1e-4, what="fused cast")
     assert_close(dbn, cast_ref.sum(0), rtol=2e-3, atol=2e-2, what="bias grad (colsum)")
     assert_close(dcs, (scaled * branch.float().cpu()).sum(0), rtol=2e-3, atol=2e-2, what="layerscale grad")
+
+
+def test_layernorm_bwd_large_plain_and_lane():
+    """DeiT configuration at scale: no LayerScale operands, column sums through the partial workspace, reduction on a side stream."""
+    from protopformer_amd import ops
+    from protopformer_amd.backbone import WgradLane
+    rows, D = 8192, 384
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).cuda(); w = (1 + 0.2 * torch.randn(D, generator=g)).cuda()
+    dy = torch.randn(rows, D, generator=g).bfloat16().cuda(); dres = torch.randn(rows, D, generator=g).cuda()
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = torch.zeros(D, device="cuda", requires_grad=True)
+    O.layer_norm(xr, wr, br).backward(dy.float())
+    mean = x.mean(-1); rstd = 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6)
+    for lane in (None, WgradLane(x.device)):
+        dw = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda"); dbn = torch.zeros(D, device="cuda")
+        dx = torch.empty(rows, D, device="cuda"); cast = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+        ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres_in=dres, dx_out=dx, cast_out=cast, dbias_next=dbn, lane=lane)
+        if lane is not None:
+            lane.join()
+        dx_ref = xr.grad + dres
+        assert_close(dx, dx_ref, rtol=1e-3, atol=1e-4, what="ln dx")
+        assert_close(dw, wr.grad, rtol=1e-3, atol=2e-3, what="ln dw")
+        assert_close(db, br.grad, rtol=1e-3, atol=2e-3, what="ln db")
+        assert_close(dbn, dx_ref.bfloat16().float().sum(0), rtol=2e-3, atol=5e-2, what="bias grad (colsum)")
+    dw2 = torch.zeros(D, device="cuda"); db2 = torch.zeros(D, device="cuda"); dbn2 = torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dw2, db2, dres_in=dres, dx_out=dx, cast_out=cast, dbias_next=dbn2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dbn, dbn2)      # ordered reduce: bit-identical
 
 
 def test_layernorm_gather_rows():
