@@ -1,1 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_norm_elementwise.py -q -x 2>&1 | tail -8 | cut -c1-300
+echo "--- KW=2"; PPF_GEMM_KW=2 timeout 300 python scripts/bench_gemm.py 2>&1 | tail -14
+echo "--- KW=1"; timeout 300 python scripts/bench_gemm.py 2>&1 | tail -14
