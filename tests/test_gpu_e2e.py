@@ -154,3 +154,18 @@ def test_real_shape_train_step_vs_oracle():
     worst_cos = min(c for _, c in rows.values())
     # measured: cosine >= 0.997 for every tensor, rel-to-max error median 3e-2, worst 0.2 (bf16 drift over 12 peaky layers)
     assert worst_cos > 0.99 and rels[len(rels) // 2] < 6e-2 and rels[-1] < 0.3, (rels[len(rels) // 2], rels[-1], worst_cos)
+
+
+def test_two_rank_data_parallel_on_one_gpu():
+    """GradSync + the weight-gradient lane with two real processes (gloo over one GPU; RCCL refuses duplicate devices):
+    identical parameters on both ranks after three steps, and averaged per-rank gradients == full-batch gradients."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29591", os.path.join(root, "scripts", "gpu", "ddp_gloo_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    m = re.search(r"ranks identical after 3 steps: (\w+); loss ([0-9.]+); cos\(.*\) = ([0-9.]+)", out)
+    assert m, out[-3000:]
+    assert m.group(1) == "True" and float(m.group(3)) > 0.9999
