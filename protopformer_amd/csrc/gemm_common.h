@@ -60,7 +60,11 @@ __device__ __forceinline__ EpiRow epi_load_row(const GemmParams& p, int m, int n
             if (p.rowscale) r.rowscale = p.rowscale[m / p.rows_per_group];
         }
     } else if constexpr (EPI == EPI_DGELU) {
-        if (ok) r.aux = *reinterpret_cast<const uint2*>(p.aux_in + (size_t)m * p.ldaux + n0);
+        if (ok) {                                 // read once, 10 ms after it was written: streaming load
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p.aux_in + (size_t)m * p.ldaux + n0));
+            r.aux = make_uint2(t.x, t.y);
+        }
     }
     return r;
 }
@@ -90,7 +94,10 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
         gelu_erf_both2(ppf_float2{v[0], v[1]}, g01, d01);
         gelu_erf_both2(ppf_float2{v[2], v[3]}, g23, d23);
         const float g[4] = {g01.x, g01.y, g23.x, g23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
-        *reinterpret_cast<uint2*>(p.aux_out + (size_t)m * p.ldaux + n0) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+        // gelu' is not read again before the backward pass: streaming (non-temporal) store, keeps L2 / MALL for the operands
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 dv = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+        __builtin_nontemporal_store(dv, reinterpret_cast<u32x2*>(p.aux_out + (size_t)m * p.ldaux + n0));
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
     } else if constexpr (EPI == EPI_SIGMOID_F32) {
 #pragma unroll

@@ -1,1 +1,2 @@
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 scripts/gpu/ddp_gloo_check.py 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -6
+timeout 300 python scripts/gpu/ln_bench.py 2>&1 | tail -1
+timeout 300 python scripts/gpu/ln_bench.py 2>&1 | tail -1
