@@ -8,10 +8,12 @@
 // which covers the three GEMMs of a Linear layer without any transposed copies:
 //   forward  y  = x W^T       : TA=0 (x [M][K]),      TB=0 (W [N][K])
 //   dgrad    dx = dy W        : TA=0 (dy [M][N]),     TB=1 (W [N=kc][K=n'])
-//   wgrad    dW = dy^T x      : TA=1 (dy [M=kc][N]),  TB=1 (x [M=kc][K]), split over kc with fp32 atomics
+//   wgrad    dW = dy^T x      : TA=1 (dy [M=kc][N]),  TB=1 (x [M=kc][K]), split over kc: fp32 partial tiles in a workspace +
+//                               an ordered reduce kernel (deterministic); fp32 atomics only without a workspace
 //
 // Tiling: 128x128x64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles),
-// register-staged global->LDS double buffering (one barrier per K tile), XOR-swizzled LDS images:
+// next K tile prefetched into registers while the current one is multiplied out of a single LDS image (32 KiB: three
+// workgroups per CU -- measured faster than an LDS double buffer at two), XOR-swizzled LDS images:
 //   mode 0 tile [128 r][64 kc]  (128 B rows): 16-B chunk index ^= (r>>1)&7  -> conflict-free ds_read_b128
 //   mode 1 tile [64 kc][128 r]  (256 B rows): 64-B unit index  ^= kc&3      -> conflict-free tr-reads
 // MFMA operands are swapped (first = B/n, second = A/m) so each lane ends up with 4 consecutive n of one

@@ -8,7 +8,7 @@ from . import _lib
 EPI_BF16, EPI_F32, EPI_GELU, EPI_SIGMOID_F32, EPI_RESID, EPI_DGELU, EPI_ATOMIC = range(7)
 
 
-# bench.py's roofline probe: HIP events (on the launch stream) around every launch of one GEMM instantiation
+# the kernel bench.py's roofline probe (ppf_gemm_probe, HIP events inside the C entry point) reports on
 DOMINANT_NAME = "gemm_kernel<TA=1,TB=1,EPI_ATOMIC,COLSUM> (weight-gradient bf16 MFMA GEMM, split over the contraction)"
 
 
