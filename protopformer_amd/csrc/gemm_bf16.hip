@@ -244,6 +244,134 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 128x128x64 tiles, both operands contraction-contiguous, FOUR workgroups per CU.  The K=384 GEMMs of this model are bound by
+// the length of each workgroup's dependent chain (load round trip -> LDS -> MFMA -> epilogue), i.e. by how many independent
+// workgroups a CU interleaves.  Loading with global_load_lds_dwordx4 removes the 32 staging registers (<= 128 VGPRs: four
+// waves per SIMD) and the ds_write pass; with a single 32 KiB LDS image per workgroup a K step is
+//   barrier -> 8 direct-to-LDS loads per thread -> vmcnt(0) + barrier -> 16 fragment reads + 16 MFMA per wave,
+// nothing of ONE workgroup overlaps, four of them do.  Swizzle on the source address (LDS image lane-linear), rows past the
+// edge re-read the last row (masked in the epilogue).  Requires K % 64 == 0.
+typedef __attribute__((address_space(3))) void g4_lds_t;
+typedef const __attribute__((address_space(1))) void g4_gbl_t;
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using IO = TileIO<false, 128>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (vid / tiles_n) * BM, n0 = (vid % tiles_n) * BN;
+    unsigned char* tA = smem;
+    unsigned char* tB = smem + TILE_BYTES;
+
+    unsigned offA[4], offB[4];
+    {
+        const int rb = tid >> 3, ch = (tid & 7) ^ ((rb >> 1) & 7);       // rows rb + 32 i share the swizzle
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ra = min(m0 + rb + 32 * i, p.M - 1), rn = min(n0 + rb + 32 * i, p.N - 1);
+            offA[i] = ((unsigned)ra * (unsigned)p.lda + ch * 8) * 2u;
+            offB[i] = ((unsigned)rn * (unsigned)p.ldb + ch * 8) * 2u;
+        }
+    }
+    const unsigned char* gA = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* gB = reinterpret_cast<const unsigned char*>(p.B);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();                          // everyone finished reading the previous K tile
+        const unsigned char* ka = gA + (size_t)kt * (BK * 2);
+        const unsigned char* kb = gB + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((g4_gbl_t*)(ka + offA[i]), (g4_lds_t*)(tA + i * 4096 + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g4_gbl_t*)(kb + offB[i]), (g4_lds_t*)(tB + i * 4096 + wave * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = IO::frag(tA, wm + 32 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb[i] = IO::frag(tB, wn + 32 * i, ks, lane);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    const int h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * STAGE_LD);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
+                    make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+        __builtin_amdgcn_wave_barrier();
+        const int col = (lane & 15) * 4;
+        const int n = n0 + wn + col;
+        const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
+        EpiRow rr[8];
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int m = m0 + wm + 32 * mi + pass * 4 + (lane >> 4);
+            rr[pass] = epi_load_row<EPI>(p, m, n, m < p.M && n < p.N);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 4 + (lane >> 4);
+            const int m = m0 + wm + 32 * mi + r;
+            const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
+            if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI>
+int launch_g4(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm128g_kernel<EPI>;
+    constexpr int lds = (2 * TILE_BYTES) > STAGE_BYTES ? (2 * TILE_BYTES) : STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm128g): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), lds, stream, p);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+bool g4_eligible(const GemmParams& p) {
+    static const int mode = getenv("PPF_GEMM_G4") ? atoi(getenv("PPF_GEMM_G4")) : 1;
+    // measured (profiles/r1_gemm_ab.txt): -12 % at K = 384 with N >= 1152 (qkv 74 -> 65 us, fc1+GELU 151 -> 133), neutral at N = 384,
+    // +5 % at K = 1536 where the register-prefetched kernel overlaps better inside a workgroup -> short contractions only
+    if (mode == 2) return p.K % BK == 0 && !p.kpad;
+    return mode && p.K % BK == 0 && p.K <= 512 && p.N >= 512 && !p.kpad && (long long)p.M * p.lda < (1ll << 30) &&
+           (long long)p.N * p.ldb < (1ll << 30) && (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) >= 512;
+}
+
 template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
 int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch) {
     constexpr int TBM = 64 * MT;
@@ -362,6 +490,15 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
     if (!trans_a && !trans_b) {
         if (nt256_eligible(p, epi)) return launch_nt256(p, epi, stream);
+        if (g4_eligible(p)) {
+            switch (epi) {
+                case EPI_BF16: return launch_g4<EPI_BF16>(p, stream);
+                case EPI_GELU: return launch_g4<EPI_GELU>(p, stream);
+                case EPI_RESID: return launch_g4<EPI_RESID>(p, stream);
+                case EPI_DGELU: return launch_g4<EPI_DGELU>(p, stream);
+                default: break;
+            }
+        }
         switch (epi) {
             case EPI_BF16: return launch<false, false, EPI_BF16, false>(p, 1, stream);
             case EPI_F32: return launch<false, false, EPI_F32, false>(p, 1, stream);
