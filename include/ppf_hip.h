@@ -85,13 +85,15 @@ int ppf_layernorm_bwd_reduce(const float* partial, int rows, int D, float* dw, f
 /* ---- attention with the policy softmax (deit:29-60; class attention cait:50-90 with self_keep = 0) -------------
  * qkv bf16 [B*N][3D] packed q|k|v, head h at columns h*hd.  policy [B][N] in {0,1} or NULL.
  * fwd saves rowmax and 1/(sum+eps) [B][H][N]; headmean = mean over heads of the probabilities, [B][N][NP] fp32
- * (the rollout input, deit:104 `attn.mean(axis=1)`), recomputed from those statistics. */
+ * (the rollout input, deit:104 `attn.mean(axis=1)`), recomputed from those statistics.
+ * eps_n: the N of the softmax's +eps/N term (deit:42); 0 = N.  Blocks that run on the reserved tokens only (compacted after the
+ * rollout) pass the original token count so that the kept entries equal the masked full-length computation. */
 int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, int B, int H, int N, int D,
-                 int self_keep, ppf_stream_t stream);
+                 int self_keep, int eps_n, ppf_stream_t stream);
 int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax, const float* zinv, float* headmean, int NP,
-                      int B, int H, int N, int D, int self_keep, ppf_stream_t stream);
+                      int B, int H, int N, int D, int self_keep, int eps_n, ppf_stream_t stream);
 int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, const float* policy, const float* rowmax,
-                 const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, ppf_stream_t stream);
+                 const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, int eps_n, ppf_stream_t stream);
 
 /* ---- CaiT: talking-heads self-attention (cait:93-132) and class attention (cait:34-90) --------------------------------
  * th_scores: sp[b][g][q][key] = sum_h Wl[g][h]*(scale q_h.k_h) + bl[g];  th_softmax_mix (in place): sp <- softmax(sp),

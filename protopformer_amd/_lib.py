@@ -23,9 +23,9 @@ SIGS = {
     "ppf_assemble_tokens": "ppppiiiis",
     "ppf_assemble_tokens_bwd": "ppppiiiis",
     "ppf_adamw_step": "pppppp" "li" "ppp" "fff" "i" "ff" "s",
-    "ppf_attn_fwd": "ppppp" "iiiii" "s",
-    "ppf_attn_headmean": "ppppp" "i" "iiiii" "s",
-    "ppf_attn_bwd": "pppppppp" "iiiii" "s",
+    "ppf_attn_fwd": "ppppp" "iiiii" "i" "s",
+    "ppf_attn_headmean": "ppppp" "i" "iiiii" "i" "s",
+    "ppf_attn_bwd": "pppppppp" "iiiii" "i" "s",
     "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "ppp" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",

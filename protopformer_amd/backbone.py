@@ -60,41 +60,54 @@ def deit_embed(feats, store, img, saved=None):
 
 def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     """The 12 blocks with attention rollout + token reservation at `reserve_layer` (deit:209-236).
-    x fp32 [B,N,D] -> (x_out, cls_token_attn [B,N-1], idx int32 [B,k], per-layer saved activations)."""
+    x fp32 [B,N,D] -> (x_out, cls_token_attn [B,N-1], idx int32 [B,k], per-layer saved activations).
+
+    From `reserve_layer` on, the reference keeps all N tokens and masks the dropped ones out of every softmax (deit:29-43,
+    233-236); their block outputs are never read again (the head gathers the reserved rows, protopformer.py:156-162) and as keys
+    they weigh eps/N ~ 5e-9.  Those blocks therefore run on the reserved rows only ([cls, 1+idx...], N' = 1+k, no policy, the
+    softmax's eps/N term kept at the original N): same results to ~1e-6, 58 % less work in the last block.  x_out is then
+    [B, 1+k, D].  PPF_COMPACT_RESERVED=0 runs the masked full-length blocks."""
     B, N, D = x.shape
     H = feats.num_heads
-    M = B * N
     NP = (N + 3) // 4 * 4
     hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
+    compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
     policy = None
-    cls_attn = idx = None
+    cls_attn = idx = rows = None
     layers = []
-    x = x.reshape(M, D)
+    Nc, eps_n = N, 0                              # tokens per sample in the current block, N of the softmax eps term (0 = Nc)
+    x = x.reshape(B * N, D)
     lane = wgrad_lane(store)
     for i, blk in enumerate(feats.blocks):
         if i == reserve_layer:
             lane.join()
             cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1)
+            if compact:
+                rows = gather_rows_map(idx, N)
+                x = x.index_select(0, rows.long())
+                Nc, eps_n, policy = 1 + reserve_k, N, None
+        M = B * Nc
         n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
-        ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, N, D, policy=policy, self_keep=True)
+        ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, Nc, D, policy=policy, self_keep=True, eps_n=eps_n)
         if i < reserve_layer:
             # only the rollout at `reserve_layer` consumes the head-mean maps: recompute them on the side stream, under the
             # rest of this block
             lane.submit(lambda qkv=qkv, rowmax=rowmax, zinv=zinv, i=i: ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy,
                                                                                         self_keep=True, out=hm[i]), (qkv, rowmax, zinv, hm))
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
-        x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N)
+        x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
         n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
         h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
-        x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=N)
+        x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=Nc)
         if save:
             layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ao=ao, rowmax=rowmax, zinv=zinv, x1=x1, n2=n2,
-                               mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2))
+                               mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2, N=Nc, eps_n=eps_n,
+                               rows=rows if (compact and i == reserve_layer) else None))
         x = x2
     lane.join()
-    return x.reshape(B, N, D), cls_attn, idx, layers
+    return x.reshape(B, Nc, D), cls_attn, idx, layers
 
 
 def gather_rows_map(idx, N):
@@ -108,11 +121,12 @@ def gather_rows_map(idx, N):
 
 def head_tokens_fwd(ppnet, store, x, idx):
     """Final norm on the reserved rows only + add-on 1x1 conv + sigmoid (deit:238; protopformer.py:162-172).
+    x is either the full token matrix [B, N, D] (rows gathered here) or already the reserved rows [B, 1+k, D].
     Returns f fp32 [B, 1+k, Dp] (token 0 = cls) and what backward needs."""
     feats = ppnet.features
     B, N, D = x.shape
     k = idx.shape[1]
-    row_map = gather_rows_map(idx, N)
+    row_map = gather_rows_map(idx, N) if N != 1 + k else None
     nf, meanf, rstdf = ops.layernorm_fwd(x.reshape(B * N, D), feats.norm.weight, feats.norm.bias, LN_EPS, row_map=row_map)
     conv = ppnet.add_on_layers[0]
     Dp = conv.out_channels
@@ -191,8 +205,10 @@ def deit_backward(ppnet, store, saved, df):
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
     # final norm backward scatters into the (zero) residual-stream gradient; also emits the bf16 gradient of the last fc2
-    dx = torch.zeros((M, D), dtype=torch.float32, device=dev)
-    dyb = torch.zeros((M, D), dtype=torch.bfloat16, device=dev)
+    # (x_last is already the reserved rows when the last blocks ran compacted: then nothing is scattered here)
+    alloc = torch.zeros if head["row_map"] is not None else torch.empty
+    dx = alloc((M, D), dtype=torch.float32, device=dev)
+    dyb = alloc((M, D), dtype=torch.bfloat16, device=dev)
     last = feats.blocks[-1]
     lnb(dnf, x_last.reshape(M, D), feats.norm.weight, head["meanf"], head["rstdf"], store.grad_view(feats.norm.weight),
                       store.grad_view(feats.norm.bias), dx_out=dx, row_map=head["row_map"], cast_out=dyb, rowscale=layers[-1]["s2"],
@@ -202,6 +218,7 @@ def deit_backward(ppnet, store, saved, df):
         gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
     for i in range(len(layers) - 1, -1, -1):
         L, blk = layers[i], feats.blocks[i]
+        Nl = L["N"]                                       # tokens per sample in this block (1+k once compacted)
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
         _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight)
         dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
@@ -209,12 +226,13 @@ def deit_backward(ppnet, store, saved, df):
         dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
         lane.before_overwrite(dyb)
         lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
-                          store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=N,
+                          store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl,
                           dbias_next=store.grad_view(blk.attn.proj.bias))
         # attention branch: x1 = x + s1 * (attn(n1) Wp^T + bp)
         _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
         dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
-        dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, N, D, policy=L["policy"], self_keep=True)
+        dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True,
+                            eps_n=L["eps_n"])
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
         dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
@@ -222,7 +240,13 @@ def deit_backward(ppnet, store, saved, df):
             lane.before_overwrite(dyb)
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
-                              rows_per_group=N, dbias_next=store.grad_view(prev.mlp.fc2.bias))
+                              rows_per_group=Nl, dbias_next=store.grad_view(prev.mlp.fc2.bias))
+            if L["rows"] is not None:
+                # this block ran on the reserved rows: hand its input gradient back to the full token matrix (zeros elsewhere)
+                Mf = B * layers[i - 1]["N"]
+                rows64 = L["rows"].long()
+                dx = torch.zeros((Mf, D), dtype=torch.float32, device=dev).index_copy_(0, rows64, dx)
+                dyb = torch.zeros((Mf, D), dtype=torch.bfloat16, device=dev).index_copy_(0, rows64, dyb)
         else:
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
@@ -231,7 +255,9 @@ def deit_backward(ppnet, store, saved, df):
     # token assembly + patch embedding
     pe = feats.patch_embed
     Np = pe.num_patches
-    dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(N, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
+    if layers and layers[0]["rows"] is not None:          # reservation in front of block 0: the embedding sees all tokens
+        dx = torch.zeros((B * (Np + 1), D), dtype=torch.float32, device=dev).index_copy_(0, layers[0]["rows"].long(), dx)
+    dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(Np + 1, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
         gs.chunk_ready(gs.head_chunk, also=(lane.stream,))

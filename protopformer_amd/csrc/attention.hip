@@ -37,6 +37,7 @@ struct AttnParams {
     int B, H, N, D;
     int self_keep;         // 1: a masked query still attends to itself (DeiT); 0: CaiT class attention
     float scale;
+    float eps_c;           // eps / N_ref: the +eps/N term of the policy softmax; N_ref = tokens BEFORE reservation (compacted blocks pass it)
 };
 
 __device__ __forceinline__ int kswz(int row) {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, Geo<NT>::NW == 8 ? 4 : 2) void attn_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    const float c = SOFTMAX_EPS / (float)N;
+    const float c = p.eps_c;
     stage_rows<HD, true, NTHR>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
     stage_rows<HD, false, NTHR>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
     for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_headmean_kernel(const AttnParams 
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int q = q0 + (lane & 31), qc = min(q, N - 1);
     const bool active = q0 < N;
-    const float c = SOFTMAX_EPS / (float)N;
+    const float c = p.eps_c;
     for (int i = tid; i < KT * 32; i += 256) {
         const int key = key_begin + i;
         pol[i] = (key < N) ? (p.policy ? p.policy[(size_t)b * N + key] : 1.0f) : 0.0f;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dkv_kernel(const At
         kf[ks] = *reinterpret_cast<const bf16x8*>(base + p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
         vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
     }
-    const float c = SOFTMAX_EPS / (float)N;
+    const float c = p.eps_c;
     f32x16 dk[DT], dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -451,12 +452,13 @@ int dispatch(int hd, int N, const char* who, F&& f) {
     return PPF_ERR_SHAPE;
 }
 
-int fill(AttnParams& p, const void* qkv, int B, int H, int N, int D, const float* policy, float* rowmax, float* zinv, int self_keep, const char* who) {
+int fill(AttnParams& p, const void* qkv, int B, int H, int N, int D, const float* policy, float* rowmax, float* zinv, int self_keep, int eps_n, const char* who) {
     PPF_CHECK_ARG(B > 0 && H > 0 && N > 0 && D > 0 && D % H == 0 && (D % 8) == 0, PPF_ERR_SHAPE, "%s: bad shape B=%d H=%d N=%d D=%d", who, B, H, N, D);
     PPF_CHECK_ARG(qkv && rowmax && zinv, PPF_ERR_ARG, "%s: null pointer", who);
     p = AttnParams();
     p.qkv = (const bf16_t*)qkv; p.ld = 3 * D; p.policy = policy; p.rowmax = rowmax; p.zinv = zinv; p.B = B; p.H = H; p.N = N; p.D = D;
     p.self_keep = self_keep; p.scale = 1.0f / sqrtf((float)(D / H));
+    p.eps_c = SOFTMAX_EPS / (float)(eps_n > 0 ? eps_n : N);
     return 0;
 }
 
@@ -466,9 +468,9 @@ extern "C" {
 
 // O[B*N][D] = softmax_policy(Q K^T / sqrt(hd)) V from packed qkv [B*N][3D]; saves rowmax and 1/(sum+eps) [B][H][N].
 int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, int B, int H, int N, int D, int self_keep,
-                 hipStream_t stream) {
+                 int eps_n, hipStream_t stream) {
     AttnParams p;
-    int rc = fill(p, qkv, B, H, N, D, policy, rowmax, zinv, self_keep, "ppf_attn_fwd");
+    int rc = fill(p, qkv, B, H, N, D, policy, rowmax, zinv, self_keep, eps_n, "ppf_attn_fwd");
     if (rc) return rc;
     p.out = (bf16_t*)out;
     return dispatch(D / H, N, "ppf_attn_fwd", [&](auto hd, auto nt) {
@@ -481,9 +483,9 @@ int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax,
 
 // headmean[B][N][NP] = mean_h probabilities (NP = N rounded up to a multiple of 4; pad columns are written as 0).
 int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax, const float* zinv, float* headmean, int NP, int B, int H,
-                      int N, int D, int self_keep, hipStream_t stream) {
+                      int N, int D, int self_keep, int eps_n, hipStream_t stream) {
     AttnParams p;
-    int rc = fill(p, qkv, B, H, N, D, policy, (float*)rowmax, (float*)zinv, self_keep, "ppf_attn_headmean");
+    int rc = fill(p, qkv, B, H, N, D, policy, (float*)rowmax, (float*)zinv, self_keep, eps_n, "ppf_attn_headmean");
     if (rc) return rc;
     PPF_CHECK_ARG(NP >= N && NP % 4 == 0 && NP < N + 4, PPF_ERR_SHAPE, "ppf_attn_headmean: NP=%d must be N rounded up to a multiple of 4", NP);
     p.headmean = headmean; p.NP = NP;
@@ -500,9 +502,9 @@ int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax,
 
 // dqkv[B*N][3D] from dout[B*N][D]; needs out, rowmax, zinv of the forward; delta[B][H][N] is scratch.
 int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, const float* policy, const float* rowmax,
-                 const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, hipStream_t stream) {
+                 const float* zinv, float* delta, int B, int H, int N, int D, int self_keep, int eps_n, hipStream_t stream) {
     AttnParams p;
-    int rc = fill(p, qkv, B, H, N, D, policy, (float*)rowmax, (float*)zinv, self_keep, "ppf_attn_bwd");
+    int rc = fill(p, qkv, B, H, N, D, policy, (float*)rowmax, (float*)zinv, self_keep, eps_n, "ppf_attn_bwd");
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;

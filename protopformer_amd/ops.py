@@ -126,28 +126,28 @@ def assemble_tokens_bwd(dx, dpos, dcls, B, Np, D, lead):
     return dtok
 
 
-def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True):
+def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True, eps_n=0):
     """qkv bf16 [B*N, 3D] -> (out bf16 [B*N, D], rowmax, zinv [B,H,N])."""
     _chk(qkv, torch.bfloat16)
     out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
     rowmax = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     zinv = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    _lib.call("ppf_attn_fwd", qkv, out, policy, rowmax, zinv, B, H, N, D, int(self_keep))
+    _lib.call("ppf_attn_fwd", qkv, out, policy, rowmax, zinv, B, H, N, D, int(self_keep), int(eps_n))
     return out, rowmax, zinv
 
 
-def attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=None, self_keep=True, out=None):
+def attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=None, self_keep=True, out=None, eps_n=0):
     NP = (N + 3) // 4 * 4
     if out is None:
         out = torch.empty((B, N, NP), dtype=torch.float32, device=qkv.device)
-    _lib.call("ppf_attn_headmean", qkv, policy, rowmax, zinv, out, NP, B, H, N, D, int(self_keep))
+    _lib.call("ppf_attn_headmean", qkv, policy, rowmax, zinv, out, NP, B, H, N, D, int(self_keep), int(eps_n))
     return out
 
 
-def attn_bwd(qkv, out, dout, rowmax, zinv, B, H, N, D, policy=None, self_keep=True):
+def attn_bwd(qkv, out, dout, rowmax, zinv, B, H, N, D, policy=None, self_keep=True, eps_n=0):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    _lib.call("ppf_attn_bwd", qkv, out, dout, dqkv, policy, rowmax, zinv, delta, B, H, N, D, int(self_keep))
+    _lib.call("ppf_attn_bwd", qkv, out, dout, dqkv, policy, rowmax, zinv, delta, B, H, N, D, int(self_keep), int(eps_n))
     return dqkv
 
 

@@ -169,3 +169,34 @@ def test_two_rank_data_parallel_on_one_gpu():
     m = re.search(r"ranks identical after 3 steps: (\w+); loss ([0-9.]+); cos\(.*\) = ([0-9.]+)", out)
     assert m, out[-3000:]
     assert m.group(1) == "True" and float(m.group(3)) > 0.9999
+
+
+def test_reserved_token_compaction_matches_masked_blocks(monkeypatch):
+    """From the reservation layer on, the blocks run on the reserved rows only (backbone.deit_blocks_fwd); the masked full-length
+    computation of the reference (PPF_COMPACT_RESERVED=0) must give the same tokens, logits and gradients up to bf16 rounding of the
+    attention probabilities (the two softmaxes subtract different row maxima)."""
+    from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(11)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PPF_COMPACT_RESERVED", mode)
+        torch.manual_seed(3)
+        m = construct_PPNet("deit_tiny_patch16_224", pretrained=False, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[10],
+                            reserve_token_nums=[81], use_global=True, use_ppc_loss=True, global_proto_per_class=5, add_on_layers_type="regular").cuda().train()
+        for blk in m.features.blocks:
+            blk.drop_path_rate = 0.0
+        if "img" not in res:
+            res["img"] = torch.randn(4, 3, 224, 224, generator=g).cuda(); res["label"] = torch.tensor([3, 0, 19, 7]).cuda()
+        f, cls_attn, idx = m._tokens(res["img"])
+        logits, aux = m(res["img"])
+        ce = CrossEntropyLoss()(logits, res["label"])
+        cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], res["label"])
+        (ce + 0.1 * cov + 0.5 * mean).backward()
+        res[mode] = dict(f=f.detach().clone(), idx=idx.clone(), logits=logits.detach().clone(), loss=float(ce.detach()),
+                         grads=m.flat_store().grads.clone())
+    a, b = res["1"], res["0"]
+    assert torch.equal(a["idx"], b["idx"])                      # the reservation itself happens before the compaction
+    assert rel_err(a["f"], b["f"]) < 2e-2 and rel_err(a["logits"], b["logits"]) < 2e-2 and abs(a["loss"] - b["loss"]) < 2e-3 * abs(b["loss"])
+    cos = float(torch.dot(a["grads"], b["grads"]) / (a["grads"].norm() * b["grads"].norm()))
+    assert cos > 0.995, cos
