@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of the full ProtoPFormer train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config deit_small|deit_tiny|cait_xxs24] [--no-graph]
+
+With --gpus N > 1 and no torch.distributed environment, this process only LAUNCHES: it spawns N rank processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) before anything here touches the GPU, relays rank 0's
+JSON line and exits non-zero if any rank failed.  Started by `python -m torch.distributed.run ... bench.py --gpus N` it is a rank.
 
 A "step" (tools/engine_proto.py:41-81): resident synthetic batch -> forward (train branch, DropPath 0.1 active) -> CE +
 0.1*PPC_sigma + 0.5*PPC_mu -> backward -> gradient all-reduce (N > 1) -> AdamW (reference param groups) -> EMA.
-Workload = BASELINE.json configs[2]: deit_small_patch16_224, 2000x384 prototypes, 200 classes, k = 81, batch 256 per GPU
-(weak scaling), bf16 MFMA operands / fp32 accumulate, random-init weights, synthetic N(0,1) images.
-Prints ONE JSON line (rank 0) with the roofline of the dominant kernel (measured live with HIP events on the launch
-stream) and the CPU baseline (oracle port on the host cores, bounded sample).
+Default workload = BASELINE.json configs[2]: deit_small_patch16_224, 2000x384 prototypes, 200 classes, k = 81, batch 256 per GPU
+(weak scaling), bf16 MFMA operands / fp32 accumulate, random-init weights, synthetic N(0,1) images.  The step is captured once
+into a HIP graph (engine.GraphedTrainStep) and replayed; --no-graph enqueues every kernel from the host each step.
+Prints ONE JSON line (rank 0) with the roofline of the dominant kernel (HIP events on its launch stream, recorded inside the
+timed region) and the CPU baseline (oracle port on the host cores, bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,70 +27,202 @@ import time
 # multi-GPU run the weight-gradient lane could land on the main stream's queue and serialise with it.  Must be set before HIP loads.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ARCH = "deit_small_patch16_224"
-BATCH = 256
-P, DP, C, K_TOK, GPC = 2000, 384, 200, 81, 10
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
-TRAIN_GFLOP_PER_IMG = 28.10        # algorithmic FLOPs of one train step per image (deit_small, Dp=384)
+METRIC = "images/sec train step, deit_small+2000 protos, bs256, 1/2/4/8 MI355X"
+
+# BASELINE.json configs 3 (headline) / 2 / 5.  gflop = algorithmic FLOPs of one train step per image.
+CONFIGS = {
+    "deit_small": dict(arch="deit_small_patch16_224", batch=256, P=2000, Dp=384, C=200, k=81, gpc=10, layer=11, gflop=28.10,
+                       D=384, H=6, depth=12, N=197, label="BASELINE.json configs[2]"),
+    "deit_tiny": dict(arch="deit_tiny_patch16_224", batch=128, P=2000, Dp=192, C=200, k=81, gpc=10, layer=11, gflop=7.85,
+                      D=192, H=3, depth=12, N=197, label="BASELINE.json configs[1]"),
+    "cait_xxs24": dict(arch="cait_xxs24_224", batch=128, P=1960, Dp=192, C=196, k=121, gpc=5, layer=1, gflop=15.75,
+                       D=192, H=4, depth=24, N=196, label="BASELINE.json configs[4] (per-GPU shape)"),
+}
 
 
-def build(device, seed):
+def executed_gflop_per_img(cfg):
+    """FLOPs the kernels really execute: DeiT blocks from the reservation layer on run on the 1+k reserved rows only
+    (backbone.deit_blocks_fwd), so their linear parts scale with (1+k)/N and their attention with ((1+k)/N)^2."""
+    if not cfg["arch"].startswith("deit"):
+        return cfg["gflop"]
+    D, H, N = cfg["D"], cfg["H"], cfg["N"]
+    hd = D // H
+    lin = 2 * N * D * 3 * D + 2 * N * D * D + 4 * N * D * 4 * D
+    att = 4 * H * N * N * hd
+    r = (1 + cfg["k"]) / N
+    saved_fwd = (cfg["depth"] - cfg["layer"]) * (lin * (1 - r) + att * (1 - r * r))
+    return cfg["gflop"] - 3 * saved_fwd / 1e9
+
+
+def build(cfg, device, seed):
+    import torch
+    import torch.distributed as dist
     from protopformer_amd.engine import FlatAdamW, make_grad_sync
     from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
     torch.manual_seed(seed)
-    model = construct_PPNet(ARCH, pretrained=False, img_size=224, prototype_shape=(P, DP, 1, 1), num_classes=C, reserve_layers=[11],
-                            reserve_token_nums=[K_TOK], use_global=True, use_ppc_loss=True, ppc_cov_thresh=1., ppc_mean_thresh=2.,
-                            global_coe=0.5, global_proto_per_class=GPC, prototype_activation_function="log", add_on_layers_type="regular")
+    model = construct_PPNet(cfg["arch"], pretrained=False, img_size=224, prototype_shape=(cfg["P"], cfg["Dp"], 1, 1), num_classes=cfg["C"],
+                            reserve_layers=[cfg["layer"]], reserve_token_nums=[cfg["k"]], use_global=True, use_ppc_loss=True, ppc_cov_thresh=1.,
+                            ppc_mean_thresh=2., global_coe=0.5, global_proto_per_class=cfg["gpc"], prototype_activation_function="log",
+                            add_on_layers_type="regular")
     model = model.to(device)
     model.train()
     opt = FlatAdamW(model, weight_decay=0.05, ema_decay=0.99996)
-    sync = make_grad_sync(model) if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0") else None
+    sync = None
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0"):
+        sync = make_grad_sync(model, opt)            # rank-0 broadcast of parameters / optimizer state, as DDP does at wrap time
     return model, opt, CrossEntropyLoss(), sync
 
 
-def cpu_baseline(batch=16, steps=2):
-    """The oracle (a CPU port of the reference arithmetic, fp32) timed on this box's host cores on a bounded sample:
-    `steps` train steps of the same architecture / head at a reduced batch."""
+def _lscpu():
+    info = {}
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            info[k.strip()] = v.strip()
+    except Exception:
+        pass
+    try:
+        sockets, cps = int(info.get("Socket(s)", "0")), int(info.get("Core(s) per socket", "0"))
+    except ValueError:
+        sockets = cps = 0
+    return {"model": info.get("Model name", "unknown"), "sockets": sockets, "physical_cores": sockets * cps, "logical_cpus": os.cpu_count()}
+
+
+def _cpu_train_steps(arch, P, Dp, C, k, gpc, batch, warmup, steps):
+    import torch
     from oracle import ppf_oracle as O
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
-    cfg = O.make_cfg(ARCH, P, DP, C, 11, K_TOK, global_per_class=GPC)
+    cfg = O.make_cfg(arch, P, Dp, C, 11, k, global_per_class=gpc)
     sd = O.init_state_dict(cfg, seed=1028)
-    params = {k: v.clone().requires_grad_(k not in O.FROZEN_KEYS) for k, v in sd.items()}
+    params = {n: v.clone().requires_grad_(n not in O.FROZEN_KEYS) for n, v in sd.items()}
     opt = torch.optim.AdamW(O.adamw_groups(params), weight_decay=0.05, eps=1e-8)
     g = torch.Generator().manual_seed(1028)
     img = torch.randn(batch, 3, 224, 224, generator=g)
     label = torch.randint(0, C, (batch,), generator=g)
-    rates = [r for i in range(12) for r in (0.1 * i / 11,)]
-    ema = {k: v.detach().clone() for k, v in params.items()}
-    O.train_step(params, opt, img, label, cfg, droppath=O.droppath_scales(batch, rates, g), ema=ema)      # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    rates = [0.1 * i / 11 for i in range(12)]
+    ema = {n: v.detach().clone() for n, v in params.items()}
+    times = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
         O.train_step(params, opt, img, label, cfg, droppath=O.droppath_scales(batch, rates, g), ema=ema)
-    dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{steps} fp32 train steps of {ARCH}+{P}x{DP} protos at batch {batch} (oracle/ppf_oracle.py, torch CPU, {threads} threads)"}
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"img_per_s": batch / med, "median_s_per_step": med, "batch": batch, "warmup": warmup, "timed_steps": steps}
+
+
+def cpu_baseline():
+    """the oracle (fp32 CPU port of the reference arithmetic) timed on this box's host cores, same step
+    definition, >= 3 warm-up + >= 5 timed steps, median; like-for-like = deit_small 2000x384 at bs32 (the headline workload at a
+    bounded batch), plus BASELINE.json configs[0] (deit_tiny, 2000x192, bs32)."""
+    import torch
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    small = _cpu_train_steps("deit_small_patch16_224", 2000, 384, 200, 81, 10, batch=32, warmup=3, steps=5)
+    tiny = _cpu_train_steps("deit_tiny_patch16_224", 2000, 192, 200, 81, 10, batch=32, warmup=3, steps=5)
+    return {"value": small["img_per_s"], "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"median of {small['timed_steps']} fp32 train steps (after {small['warmup']} warm-up) of deit_small_patch16_224+2000x384 "
+                      f"protos at batch 32 (oracle/ppf_oracle.py, torch CPU, {threads} threads)",
+            "median_s_per_step": small["median_s_per_step"], "cpu": _lscpu(),
+            "config1_deit_tiny_bs32": {"value": tiny["img_per_s"], "median_s_per_step": tiny["median_s_per_step"],
+                                       "sample": f"median of {tiny['timed_steps']} steps after {tiny['warmup']} warm-up, deit_tiny_patch16_224+2000x192 protos, batch 32"}}
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r1_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction applied)."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    (profiles/*_pmc_traffic.json, newest round first: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction)."""
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            ks = json.load(open(path))["kernels"]
+            for kname, v in ks.items():
+                if "gemm_kernel<true, true, 7" in kname:
+                    return v["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------ launcher (N > 1, no dist env)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """Parent of a multi-GPU run: spawns one rank per GPU and relays rank 0's JSON line.  Makes NO GPU call itself."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else None,
+                                      stderr=None, text=True))
+    deadline = time.time() + args.launch_timeout
+    out0 = ""
+    rcs = [None] * len(procs)
     try:
-        ks = json.load(open(path))["kernels"]
-        for name, v in ks.items():
-            if "gemm_kernel<true, true, 7" in name:
-                return v["hbm_bytes_per_launch"]
-    except Exception:
+        out0, _ = procs[0].communicate(timeout=args.launch_timeout)
+        rcs[0] = procs[0].returncode
+        for i, p in enumerate(procs[1:], 1):
+            rcs[i] = p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
         pass
-    return None
+    finally:
+        for p in procs:                       # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed or timed out (rank, rc): {bad}\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ dry run (CPU, gloo): launch plumbing
+def dry_run(args, world, rank):
+    """The N > 1 control path without a GPU: rendezvous, chunked gradient all-reduce (engine.GradSync) over gloo, barrier +
+    max-over-ranks timing, one JSON line from rank 0.  Used by tests/test_bench_launch_cpu.py; not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from protopformer_amd.engine import GradSync
+    if world > 1:
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    g = torch.full((1 << 16,), float(rank + 1))
+    sync = GradSync(g, [0, 1 << 14, 1 << 15, 1 << 16], use_side_stream=False)
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.fill_(float(rank + 1))
+        for c in (2, 1, 0):
+            sync.chunk_ready(c)
+        scale = sync.finish()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = abs(float(g[0]) * scale - (world + 1) / 2.0) < 1e-6
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * float(dt) / max(args.steps, 1), "dry_run": True, "allreduce_ok": bool(ok), "scaling": "weak",
+                          "higher_is_better": True, "data": "synthetic"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -92,37 +230,77 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="deit_small")
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each step instead of replaying a captured HIP graph")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the multi-rank launch + all-reduce plumbing (no GPU, no measurement)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        sys.exit(dry_run(args, world, rank))
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path)")
+    cfg = dict(CONFIGS[args.config])
+    batch = args.batch or cfg["batch"]
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from protopformer_amd import _lib, ops
-    from protopformer_amd.engine import train_one_step
-    model, opt, crit, sync = build(device, seed=1028)          # same seed on every rank, as the reference (main.py:254-255)
+    from protopformer_amd.engine import GraphedTrainStep, train_one_step
+    # the reference seeds every rank with seed + rank (main.py:254) and relies on DDP's rank-0 broadcast (main.py:370) to make the
+    # replicas identical; same here: make_grad_sync() broadcasts rank 0's parameters / optimizer state
+    model, opt, crit, sync = build(cfg, device, seed=1028 + rank)
     g = torch.Generator(device=device).manual_seed(1028 + rank)
-    img = torch.randn(args.batch, 3, 224, 224, device=device, generator=g)
-    label = torch.randint(0, C, (args.batch,), device=device, generator=g)
+    img = torch.randn(batch, 3, 224, 224, device=device, generator=g)
+    label = torch.randint(0, cfg["C"], (batch,), device=device, generator=g)
+
+    graphed = None
+    graph_note = "eager (--no-graph)"
+    if not args.no_graph:
+        graphed = GraphedTrainStep(model, crit, opt, epoch=20, grad_sync=sync, warmup=2, adopt_inputs=True)     # the batch is resident
 
     def step():
+        if graphed is not None:
+            return graphed(img, label)
         return train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
 
-    for _ in range(args.warmup):
+    # warm-up: two eager steps, then (graph mode) the capture with the roofline probe ON -- its HIP events become event-record
+    # nodes that every replay re-records on the weight-gradient stream -- then the remaining warm-up replays
+    done = 0
+    if graphed is not None:
+        try:
+            for _ in range(2):
+                step(); done += 1
+            _lib.call("ppf_gemm_probe", 1)
+            step(); done += 1                                         # capture + first replay
+            _lib.call("ppf_gemm_probe", 0)
+            torch.cuda.synchronize()
+            graph_note = "one captured HIP graph per step (engine.GraphedTrainStep), replayed"
+        except Exception as e:                                        # capture refused (e.g. a collective that cannot be captured)
+            _lib.call("ppf_gemm_probe", 0)
+            graph_note = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:200]})"
+            graphed = None
+            torch.cuda.synchronize()
+    for _ in range(max(0, args.warmup - done)):
         step()
-    # roofline probe: HIP events around every launch of the dominant kernel (wgrad GEMM) on its launch stream
-    _lib.call("ppf_gemm_probe", 1)
+    if graphed is None:
+        _lib.call("ppf_gemm_probe", 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -134,30 +312,44 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    _lib.call("ppf_gemm_probe", 0)
+    if graphed is None:
+        _lib.call("ppf_gemm_probe", 0)
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     import ctypes
     c_ms, c_n, c_fl, c_by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-    _lib.call("ppf_gemm_probe_read", ctypes.addressof(c_ms), ctypes.addressof(c_n), ctypes.addressof(c_fl), ctypes.addressof(c_by))
+    probe_note = "HIP events around every launch inside the timed region" if graphed is None else \
+        "HIP event-record nodes of the captured step: durations of the launches of the LAST timed replay"
+    try:
+        _lib.call("ppf_gemm_probe_read", ctypes.addressof(c_ms), ctypes.addressof(c_n), ctypes.addressof(c_fl), ctypes.addressof(c_by))
+    except RuntimeError as e:
+        probe_note = f"probe read failed: {e}"
     kern_ms, n_launch, probe_flops, probe_bytes = c_ms.value, int(c_n.value), c_fl.value, c_by.value
     if rank == 0:
-        ips = world * args.batch * args.steps / dt
+        ips = world * batch * args.steps / dt
         achieved = (probe_flops / 1e12) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic() if args.config == "deit_small" else (None, None)
+        ex = executed_gflop_per_img(cfg)
         out = {
-            "metric": "images/sec train step, deit_small+2000 protos, bs256, 1/2/4/8 MI355X", "value": ips, "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps, "higher_is_better": True,
+            "metric": METRIC, "value": ips, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{ARCH}, synthetic 224x224, {P}x{DP} prototypes, {C} classes, k={K_TOK}, batch {args.batch}/GPU, "
-                                   "train step = fwd+CE+PPC+bwd+allreduce+AdamW+EMA, DropPath 0.1", "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}"},
+            "config": {"workload": f"{cfg['arch']}, synthetic 224x224, {cfg['P']}x{cfg['Dp']} prototypes, {cfg['C']} classes, k={cfg['k']}, batch {batch}/GPU "
+                                   f"({cfg['label']}), train step = fwd+CE+PPC+bwd+allreduce+AdamW+EMA, DropPath 0.1; blocks after the token "
+                                   "reservation run compacted on the 1+k reserved rows (equal to the masked full-length blocks to bf16 rounding)",
+                       "global_batch": world * batch, "parallelism": f"dp{world}", "execution": graph_note},
             "roofline": {"bound": "mfma", "kernel": ops.DOMINANT_NAME, "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(), "traffic_unit": "bytes/launch (PMC, see profiles/r1_pmc_traffic.json)",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "traffic_unit": f"bytes/launch (PMC, see profiles/{traffic_src})" if traffic_src else None,
                          "algorithmic_bytes": probe_bytes / max(n_launch, 1), "launches": n_launch,
-                         "avg_launch_ms": kern_ms / max(n_launch, 1)},
-            "step_mfma_frac": (ips / world) * TRAIN_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS,
+                         "avg_launch_ms": kern_ms / max(n_launch, 1),
+                         "how": probe_note + "; the kernel runs on the weight-gradient stream concurrently with the main chain (contended time)"},
+            "step_mfma_frac": (ips / world) * cfg["gflop"] / 1e3 / PEAK_BF16_TFLOPS,
+            "step_mfma_frac_executed": (ips / world) * ex / 1e3 / PEAK_BF16_TFLOPS,
+            "gflop_per_img": {"algorithmic": cfg["gflop"], "executed": ex},
             "final_loss": float(loss),
         }
         if world == 1 and not args.no_cpu_baseline:

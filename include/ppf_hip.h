@@ -51,9 +51,11 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
 /* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic two-pass reduction instead of atomics) */
 size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
-/* Roofline probe of the split-K weight-gradient kernel (epi 6 with a workspace): HIP events on the launch stream around the
- * kernel itself.  ppf_gemm_probe(1) clears and starts, (0) stops; ppf_gemm_probe_read synchronises the events and returns the
- * summed kernel time, the launch count and the algorithmic flops / bytes of those launches (bench.py's `roofline`). */
+/* Roofline probe of the split-K weight-gradient kernel (epi 6 with a workspace): HIP events (from a reused pool) on the launch
+ * stream around the kernel itself.  ppf_gemm_probe(1) clears and starts, (0) stops, (2) stops and destroys the pool;
+ * ppf_gemm_probe_read synchronises the events and returns the summed kernel time, the launch count and the algorithmic
+ * flops / bytes of those launches (bench.py's `roofline`).  Enabled while a step is being captured into a HIP graph, the records
+ * become event-record nodes: a read after replays returns the last replay's durations. */
 int ppf_gemm_probe(int enable);
 int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, double* bytes);
 
@@ -155,12 +157,59 @@ int ppf_assemble_tokens(const float* tok, const float* cls, const float* pos, fl
                         ppf_stream_t stream);
 int ppf_assemble_tokens_bwd(const float* dx, void* dtok, float* dpos, float* dcls, int B, int Np, int D, int lead,
                             ppf_stream_t stream);
-/* backward of the add-on Sigmoid (protopformer.py:113): dz = bf16(df*f*(1-f)), dbias += column sums */
-int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int rows, int cols, ppf_stream_t stream);
+/* backward of the add-on Sigmoid (protopformer.py:113): dz = bf16(df*f*(1-f)), dbias += column sums.  partial (>=
+ * ppf_sigmoid_bwd_blocks(rows)*cols floats) makes the column sums a fixed-order two-pass reduction; NULL = fp32 atomics. */
+int ppf_sigmoid_bwd_blocks(int rows);
+int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int rows, int cols, float* partial, size_t partial_bytes,
+                    ppf_stream_t stream);
 /* fused AdamW (+EMA, +bf16 re-cast) over flat buffers (tools/create_optimizer.py:92, engine_proto.py:80-81) */
 int ppf_adamw_step(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
                    const int64_t* seg_bounds, const float* seg_lr, const float* seg_wd, float beta1, float beta2, float eps,
                    int step, float ema_decay, float grad_scale, ppf_stream_t stream);
+/* The same step with every step-dependent scalar in DEVICE memory: hyper[0..7] lr per segment, [8..15] weight decay per segment,
+ * [16] 1-beta1^t, [17] sqrt(1-beta2^t), [18] gradient scale (1/world), [19] clip coefficient (ppf_clip_grad_scale; 1 = off).
+ * Nothing step-dependent is baked into the launch, so a captured HIP graph of the train step can be replayed
+ * (lr schedule tools/create_scheduler.py:20-32 keeps working: the host refreshes `hyper` before each replay). */
+int ppf_adamw_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
+                       const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
+                       ppf_stream_t stream);
+/* hyper[0..n) <- host_vals[0..n) (n <= 20), passed by value at enqueue time (safe when the host runs ahead of the device) */
+int ppf_hyper_set(float* hyper, const float* host_vals, int n, ppf_stream_t stream);
+/* clip_grad_norm_ (timm dispatch_clip_grad 'norm' via NativeScaler, engine_proto.py:74-76, main.py --clip-grad): hyper[19] =
+ * min(1, max_norm / (pre_scale*||g||_2 + 1e-6)); partial = ppf_clip_grad_blocks() floats of scratch; norm_out optional. */
+int ppf_clip_grad_blocks(void);
+int ppf_clip_grad_scale(const float* g, int64_t n, float max_norm, float pre_scale, float* partial, float* hyper, float* norm_out,
+                        ppf_stream_t stream);
+/* timm DropPath factors floor(keep+U)/keep for all (slot, sample) pairs of one step (deit:71,79-80): out [nslot][B], keep [nslot]
+ * (device).  Philox4x32-10 keyed by seed, counter = (state_u64[0], element); the launch advances state_u64[0] (device) by one. */
+int ppf_droppath_scales(float* out, const float* keep, int nslot, int B, uint64_t seed, void* state_u64, ppf_stream_t stream);
+/* token reservation plumbing (protopformer.py:156-162 gather of [cls, 1+idx...]): flat source rows of the reserved tokens,
+ * row gather, and zero-filled row scatter (its backward). row_bytes % 16 == 0. */
+int ppf_reserved_rows_map(const int* idx, int* rows, int B, int k, int N, ppf_stream_t stream);
+int ppf_gather_rows(const void* src, const int* rows, void* dst, int nrows, int row_bytes, ppf_stream_t stream);
+int ppf_scatter_rows(const void* src, const int* rows, void* dst, int nrows_src, int nrows_dst, int row_bytes, ppf_stream_t stream);
+int ppf_memset_zero(void* ptr, size_t bytes, ppf_stream_t stream);
+/* out = x * (*scalar_dev): chain rule with a device-resident upstream scalar (autograd of nn.CrossEntropyLoss, main.py:390) */
+int ppf_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, ppf_stream_t stream);
+
+/* ---- fp32 verification path (forward only; PPNet.precise / PPF_PRECISE=1) ------------------------------------------------
+ * Every operand and intermediate fp32, contractions through ppf_sgemm, exact-erf GELU: used by the parity tests to hold the whole
+ * forward / loss to 1e-3 rel against the reference fixtures.  Same reference lines as the bf16 kernels above. */
+int ppf_im2col_patch_f32(const float* img, float* cols, int B, int C, int H, int W, int patch, ppf_stream_t stream);
+int ppf_layernorm_fwd_f32(const float* x, const int* row_map, const float* w, const float* b, float* y, int rows, int D, float eps,
+                          ppf_stream_t stream);
+/* in place on C[M][N]: kind 0 +bias | 1 gelu_erf(+bias) | 2 sigmoid(+bias) | 3 res + rowscale[m/rows_per_group]*colscale[n]*(C+bias) */
+int ppf_epilogue_f32(float* C, const float* bias, int kind, const float* res, const float* rowscale, int rows_per_group,
+                     const float* colscale, int M, int N, ppf_stream_t stream);
+/* deit:29-60 on fp32 qkv [B*N][3D]; headmean (optional) [B][N][NP] = mean over heads of the probabilities (deit:104) */
+int ppf_attn_fwd_f32(const float* qkv, float* out, const float* policy, float* headmean, int NP, int B, int H, int N, int D,
+                     int self_keep, int eps_n, ppf_stream_t stream);
+/* cait:115-132 on fp32 qkv; headmean = mean over heads of the returned (post proj_w) attention (cait:328) */
+int ppf_th_attn_fwd_f32(const float* qkv, const float* wl, const float* bl, const float* ww, const float* bw, float* out,
+                        float* headmean, int NP, int B, int H, int N, int D, ppf_stream_t stream);
+/* cait:50-90: q [B][D] cls rows, k / v [B*N1][D]; attn_mean [B][N1] = mean over heads of the probabilities */
+int ppf_class_attn_fwd_f32(const float* q, const float* k, const float* v, const float* policy, float* attn_mean, float* out, int B,
+                           int H, int N1, int D, ppf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,10 +43,25 @@ SIGS = {
     "ppf_class_attn_fwd": "pppppppp" "iiii" "s",
     "ppf_class_attn_bwd": "ppppppppp" "iiii" "s",
     "ppf_merge3_cast": "pppp" "iii" "s",
-    "ppf_sigmoid_bwd": "ppppiis",
+    "ppf_sigmoid_bwd": "ppppii" "pz" "s",
+    "ppf_im2col_patch_f32": "pp" "iiiii" "s",
+    "ppf_layernorm_fwd_f32": "ppppp" "iif" "s",
+    "ppf_epilogue_f32": "pp" "i" "pp" "i" "p" "ii" "s",
+    "ppf_attn_fwd_f32": "pppp" "i" "iiii" "ii" "s",
+    "ppf_th_attn_fwd_f32": "ppppp" "pp" "i" "iiii" "s",
+    "ppf_class_attn_fwd_f32": "pppppp" "iiii" "s",
+    "ppf_adamw_step_dev": "pppppp" "li" "pp" "ffff" "s",
+    "ppf_hyper_set": "ppi" "s",
+    "ppf_clip_grad_scale": "pl" "ff" "ppp" "s",
+    "ppf_droppath_scales": "pp" "ii" "Lp" "s",
+    "ppf_reserved_rows_map": "pp" "iii" "s",
+    "ppf_gather_rows": "ppp" "ii" "s",
+    "ppf_scatter_rows": "ppp" "iii" "s",
+    "ppf_memset_zero": "pz" "s",
+    "ppf_scale_by_scalar": "ppp" "l" "s",
 }
 
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
 
 
@@ -63,6 +78,10 @@ def lib():
         _lib.ppf_gemm_workspace_bytes.argtypes = [ctypes.c_int] * 3
         _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int
         _lib.ppf_layernorm_bwd_blocks.argtypes = [ctypes.c_int]
+        _lib.ppf_sigmoid_bwd_blocks.restype = ctypes.c_int
+        _lib.ppf_sigmoid_bwd_blocks.argtypes = [ctypes.c_int]
+        _lib.ppf_clip_grad_blocks.restype = ctypes.c_int
+        _lib.ppf_clip_grad_blocks.argtypes = []
         for name, spec in SIGS.items():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_int

@@ -19,17 +19,19 @@ _KEEP_CACHE = {}
 
 def droppath_scales(rates, B, device, training):
     """Per-layer, per-sample DropPath factors floor(keep + U)/keep (timm DropPath); None where the rate is 0.
-    Returns (scales [n_active, B] tensor or None, index map layer-slot -> row or -1)."""
+    Returns (scales [n_active, B] tensor or None, index map layer-slot -> row or -1).
+    The draws come from the library's Philox kernel (ops.droppath_draw) keyed by torch.initial_seed(); the step counter lives in
+    device memory and is advanced by the launch itself, so a captured HIP graph of the step replays fresh draws."""
     slots = [r if training else 0.0 for r in rates]
     active = [i for i, r in enumerate(slots) if r > 0.0]
     if not active:
         return None, [-1] * len(slots)
     key = (tuple(slots), str(device))
-    keep = _KEEP_CACHE.get(key)
-    if keep is None:            # the H2D copy of a fresh host tensor is a blocking call: build the constant once per schedule
-        keep = _KEEP_CACHE[key] = torch.tensor([1.0 - slots[i] for i in active], device=device, dtype=torch.float32)[:, None]
-    u = torch.rand(len(active), B, device=device, dtype=torch.float32)
-    scales = (torch.floor(keep + u) / keep).contiguous()
+    st = _KEEP_CACHE.get(key)
+    if st is None:              # the H2D copy of a fresh host tensor is a blocking call: build the constants once per schedule
+        st = _KEEP_CACHE[key] = dict(keep=torch.tensor([1.0 - slots[i] for i in active], device=device, dtype=torch.float32),
+                                     state=torch.zeros(1, dtype=torch.int64, device=device), seed=torch.initial_seed())
+    scales = ops.droppath_draw(torch.empty((len(active), B), dtype=torch.float32, device=device), st["keep"], st["seed"], st["state"])
     index = [-1] * len(slots)
     for row, i in enumerate(active):
         index[i] = row
@@ -58,7 +60,7 @@ def deit_embed(feats, store, img, saved=None):
     return x
 
 
-def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
+def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact=None):
     """The 12 blocks with attention rollout + token reservation at `reserve_layer` (deit:209-236).
     x fp32 [B,N,D] -> (x_out, cls_token_attn [B,N-1], idx int32 [B,k], per-layer saved activations).
 
@@ -66,12 +68,14 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     233-236); their block outputs are never read again (the head gathers the reserved rows, protopformer.py:156-162) and as keys
     they weigh eps/N ~ 5e-9.  Those blocks therefore run on the reserved rows only ([cls, 1+idx...], N' = 1+k, no policy, the
     softmax's eps/N term kept at the original N): same results to ~1e-6, 58 % less work in the last block.  x_out is then
-    [B, 1+k, D].  PPF_COMPACT_RESERVED=0 runs the masked full-length blocks."""
+    [B, 1+k, D].  compact=False (or PPF_COMPACT_RESERVED=0) runs the masked full-length blocks and returns all N tokens, as the
+    reference's forward_feature_mask_train_direct does."""
     B, N, D = x.shape
     H = feats.num_heads
     NP = (N + 3) // 4 * 4
     hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
-    compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
+    if compact is None:
+        compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
     policy = None
     cls_attn = idx = rows = None
     layers = []
@@ -83,8 +87,8 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
             lane.join()
             cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1)
             if compact:
-                rows = gather_rows_map(idx, N)
-                x = x.index_select(0, rows.long())
+                rows = ops.reserved_rows_map(idx, N)
+                x = ops.gather_rows(x, rows)
                 Nc, eps_n, policy = 1 + reserve_k, N, None
         M = B * Nc
         n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
@@ -113,10 +117,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
 def gather_rows_map(idx, N):
     """Source-row map of the reserved tokens: per sample [cls, 1+idx...] as flat rows of the [B*N] token matrix
     (integer index plumbing of protopformer.py:156-162)."""
-    B, k = idx.shape
-    base = torch.arange(B, device=idx.device, dtype=torch.int32)[:, None] * N
-    rows = torch.cat([base, base + 1 + idx], dim=1)
-    return rows.reshape(-1).contiguous()
+    return ops.reserved_rows_map(idx, N)
 
 
 def head_tokens_fwd(ppnet, store, x, idx):
@@ -206,9 +207,9 @@ def deit_backward(ppnet, store, saved, df):
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
     # final norm backward scatters into the (zero) residual-stream gradient; also emits the bf16 gradient of the last fc2
     # (x_last is already the reserved rows when the last blocks ran compacted: then nothing is scattered here)
-    alloc = torch.zeros if head["row_map"] is not None else torch.empty
-    dx = alloc((M, D), dtype=torch.float32, device=dev)
-    dyb = alloc((M, D), dtype=torch.bfloat16, device=dev)
+    alloc = ops.zeros if head["row_map"] is not None else (lambda shape, dtype, device: torch.empty(shape, dtype=dtype, device=device))
+    dx = alloc((M, D), torch.float32, dev)
+    dyb = alloc((M, D), torch.bfloat16, dev)
     last = feats.blocks[-1]
     lnb(dnf, x_last.reshape(M, D), feats.norm.weight, head["meanf"], head["rstdf"], store.grad_view(feats.norm.weight),
                       store.grad_view(feats.norm.bias), dx_out=dx, row_map=head["row_map"], cast_out=dyb, rowscale=layers[-1]["s2"],
@@ -244,9 +245,8 @@ def deit_backward(ppnet, store, saved, df):
             if L["rows"] is not None:
                 # this block ran on the reserved rows: hand its input gradient back to the full token matrix (zeros elsewhere)
                 Mf = B * layers[i - 1]["N"]
-                rows64 = L["rows"].long()
-                dx = torch.zeros((Mf, D), dtype=torch.float32, device=dev).index_copy_(0, rows64, dx)
-                dyb = torch.zeros((Mf, D), dtype=torch.bfloat16, device=dev).index_copy_(0, rows64, dyb)
+                dx = ops.scatter_rows(dx, L["rows"], Mf)
+                dyb = ops.scatter_rows(dyb, L["rows"], Mf)
         else:
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
@@ -256,7 +256,7 @@ def deit_backward(ppnet, store, saved, df):
     pe = feats.patch_embed
     Np = pe.num_patches
     if layers and layers[0]["rows"] is not None:          # reservation in front of block 0: the embedding sees all tokens
-        dx = torch.zeros((B * (Np + 1), D), dtype=torch.float32, device=dev).index_copy_(0, layers[0]["rows"].long(), dx)
+        dx = ops.scatter_rows(dx, layers[0]["rows"], B * (Np + 1))
     dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(Np + 1, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:

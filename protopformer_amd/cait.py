@@ -236,7 +236,7 @@ def cait_backward(ppnet, store, saved, df):
     dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), gv(conv.bias))
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
-    du = torch.zeros((B * N1, D), dtype=torch.float32, device=dev)
+    du = ops.zeros((B * N1, D), torch.float32, dev)
     lnb(dnf, u_last.reshape(B * N1, D), feats.norm.weight, head["meanf"], head["rstdf"], gv(feats.norm.weight),
                       gv(feats.norm.bias), dx_out=du, row_map=head["row_map"])
     du3 = du.reshape(B, N1, D)

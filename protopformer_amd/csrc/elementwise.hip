@@ -47,24 +47,26 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
     }
 }
 
-// dx [B][T][D] -> dtok bf16 [B*Np][D] (rows t >= lead), dpos[t] += sum_b dx[b][t], dcls += sum_b dx[b][0] (lead = 1)
+// dx [B][T][D] -> dtok bf16 [B*Np][D] (rows t >= lead), dpos[t] += sum_b dx[b][t], dcls += sum_b dx[b][0] (lead = 1).
+// One thread owns a column pair of one token and walks the batch in order: a single writer per output, fixed summation order
+// (no float atomics -> bit-identical from run to run).
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dtok,
                                                            float* __restrict__ dpos, float* __restrict__ dcls, int B, int Np,
-                                                           int D, int lead, int bchunk) {
+                                                           int D, int lead) {
     const int T = Np + lead, d2 = D / 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= T * d2) return;
     const int c = (i % d2) * 2, t = i / d2;
-    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
     float2 acc = make_float2(0.f, 0.f);
-    for (int b = b0; b < b1; ++b) {
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {
         const float2 v = *reinterpret_cast<const float2*>(dx + ((size_t)b * T + t) * D + c);
         acc.x += v.x; acc.y += v.y;
         if (t >= lead) *reinterpret_cast<uint32_t*>(dtok + ((size_t)b * Np + (t - lead)) * D + c) = pack_bf16x2(v.x, v.y);
     }
-    unsafeAtomicAdd(dpos + (size_t)t * D + c, acc.x);
-    unsafeAtomicAdd(dpos + (size_t)t * D + c + 1, acc.y);
-    if (t < lead && dcls) { unsafeAtomicAdd(dcls + c, acc.x); unsafeAtomicAdd(dcls + c + 1, acc.y); }
+    float* dp = dpos + (size_t)t * D + c;
+    dp[0] += acc.x; dp[1] += acc.y;
+    if (t < lead && dcls) { dcls[c] += acc.x; dcls[c + 1] += acc.y; }
 }
 
 // Fused AdamW (decoupled weight decay, torch.optim.AdamW semantics) over a flat parameter buffer split in
@@ -75,8 +77,17 @@ struct AdamParams {
     float* p; const float* g; float* m; float* v; float* ema; bf16_t* p16;
     int64_t n; int nseg; Seg seg[MAX_SEGS];
     float beta1, beta2, eps, bc1, bc2_sqrt, ema_decay, grad_scale;
+    const float* hyper;          // device-resident step state (PPF_HYPER_* layout) or NULL: then the scalars above are used
 };
-__global__ __launch_bounds__(256) void adamw_kernel(const AdamParams a) {
+// hyper[0..7] lr per segment, [8..15] weight decay per segment, [16] 1-beta1^t, [17] sqrt(1-beta2^t), [18] gradient scale
+// (1/world), [19] clip factor written by clip_finish_kernel (1 when clipping is off).  Reading them from memory lets a
+// captured HIP graph of the step be replayed with a new step count / learning rate (the host refreshes hyper before a replay).
+__global__ __launch_bounds__(256) void adamw_kernel(AdamParams a) {
+    if (a.hyper) {
+#pragma unroll
+        for (int s = 0; s < MAX_SEGS; ++s) { a.seg[s].lr = a.hyper[s]; a.seg[s].wd = a.hyper[8 + s]; }
+        a.bc1 = a.hyper[16]; a.bc2_sqrt = a.hyper[17]; a.grad_scale = a.hyper[18] * a.hyper[19];
+    }
     const int64_t n4 = a.n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const int64_t e0 = i * 4;
@@ -109,9 +120,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamParams a) {
     }
 }
 
-// dz = bf16(df * f * (1 - f)) for f = sigmoid(z); dbias[c] += column sums of the rounded dz (bias grad of the add-on layer)
+// dz = bf16(df * f * (1 - f)) for f = sigmoid(z); dbias[c] += column sums of the rounded dz (bias grad of the add-on layer).
+// partial != NULL: each workgroup writes its column sums to partial[block][cols] and sigmoid_bias_reduce_kernel adds them in a
+// fixed order (deterministic); partial == NULL: fp32 atomics.
 __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ df, const float* __restrict__ f, bf16_t* __restrict__ dz,
-                                                          float* __restrict__ dbias, int rows, int cols, int rows_per_block) {
+                                                          float* __restrict__ dbias, float* __restrict__ partial, int rows, int cols,
+                                                          int rows_per_block) {
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int c = threadIdx.x; c < cols; c += 256) {
         float acc = 0.f;
@@ -122,8 +136,111 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
             dz[o] = h;
             acc += bf16_to_f32(h);
         }
-        if (dbias) unsafeAtomicAdd(dbias + c, acc);
+        if (partial) partial[(size_t)blockIdx.x * cols + c] = acc;
+        else if (dbias) unsafeAtomicAdd(dbias + c, acc);
     }
+}
+__global__ __launch_bounds__(256) void sigmoid_bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int nblk, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.f;
+    for (int b = 0; b < nblk; ++b) acc += partial[(size_t)b * cols + c];
+    dbias[c] += acc;
+}
+
+// ---- global gradient-norm clipping (timm NativeScaler / dispatch_clip_grad, engine_proto.py:74-76): two deterministic passes
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n4, float* __restrict__ partial) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// hyper[19] = min(1, max_norm / (pre_scale * ||g|| + 1e-6))   (torch.nn.utils.clip_grad_norm_'s coefficient)
+__global__ __launch_bounds__(256) void clip_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm, float pre_scale,
+                                                          float* __restrict__ hyper, float* __restrict__ norm_out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = pre_scale * sqrtf(red[0]);
+        hyper[19] = fminf(1.0f, max_norm / (nrm + 1e-6f));
+        if (norm_out) *norm_out = nrm;
+    }
+}
+
+// ---- DropPath factors floor(keep + U) / keep (timm DropPath, deit:71,79-80) for every (slot, sample) of a step.
+// U comes from Philox4x32-10 keyed by `seed`, counter = (state[0] = step number, element index): one single-workgroup launch
+// per step that also advances the step number in device memory, so a captured graph replays fresh draws.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k.y, (uint32_t)p0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__global__ __launch_bounds__(256) void droppath_kernel(float* __restrict__ out, const float* __restrict__ keep, int nslot, int B,
+                                                       uint64_t seed, unsigned long long* __restrict__ state) {
+    const unsigned long long step = state[0];
+    const int total = nslot * B;
+    for (int i4 = threadIdx.x; i4 * 4 < total; i4 += 256) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)i4, 0u, (uint32_t)step, (uint32_t)(step >> 32)),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i4 * 4 + j;
+            if (i < total) {
+                const float kp = keep[i / B];
+                const float u = (float)(rv[j] >> 8) * (1.0f / 16777216.0f);          // [0, 1) on a 24-bit grid
+                out[i] = floorf(kp + u) / kp;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) state[0] = step + 1;
+}
+
+// ---- row gather / scatter of the token reservation (integer index plumbing of protopformer.py:156-162)
+// rows[b*(1+k)] = b*N ; rows[b*(1+k)+1+j] = b*N + 1 + idx[b][j]
+__global__ __launch_bounds__(256) void rows_map_kernel(const int* __restrict__ idx, int* __restrict__ rows, int B, int k, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * (k + 1)) return;
+    const int b = i / (k + 1), j = i % (k + 1);
+    rows[i] = b * N + (j == 0 ? 0 : 1 + idx[b * k + j - 1]);
+}
+// dst[r] = src[rows[r]] (gather) or dst[rows[r]] = src[r] (scatter); rows of `vec` 16-byte words
+__global__ __launch_bounds__(256) void move_rows_kernel(const uint4* __restrict__ src, const int* __restrict__ rows, uint4* __restrict__ dst,
+                                                        int nrows, int vec, int scatter) {
+    const int64_t total = (int64_t)nrows * vec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / vec), c = (int)(i % vec);
+        const int64_t o = (int64_t)rows[r] * vec + c;
+        if (scatter) dst[o] = src[i]; else dst[i] = src[o];
+    }
+}
+// out = x * (*scalar)   (chain rule with a device-resident upstream scalar)
+__global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ out, int64_t n) {
+    const float s = *scalar;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x[i] * s;
+}
+
+struct HyperVals { float v[20]; int n; };
+__global__ void hyper_set_kernel(float* __restrict__ hyper, const HyperVals h) {
+    if ((int)threadIdx.x < h.n) hyper[threadIdx.x] = h.v[threadIdx.x];
 }
 
 inline int grid_for(int64_t work, int per_block = 256) {
@@ -161,17 +278,22 @@ int ppf_assemble_tokens(const float* tok, const float* cls, const float* pos, fl
 int ppf_assemble_tokens_bwd(const float* dx, void* dtok, float* dpos, float* dcls, int B, int Np, int D, int lead, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && Np > 0 && D % 2 == 0 && (lead == 0 || lead == 1), PPF_ERR_SHAPE, "ppf_assemble_tokens_bwd: bad shape");
     const int T = Np + lead, threads = T * D / 2;
-    const int bchunk = 16;
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((threads + 255) / 256, (B + bchunk - 1) / bchunk), dim3(256), 0, stream, dx, (bf16_t*)dtok, dpos, dcls, B,
-                       Np, D, lead, bchunk);
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, dx, (bf16_t*)dtok, dpos, dcls, B, Np, D, lead);
     PPF_LAUNCH_CHECK();
     return 0;
 }
 
-int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int rows, int cols, hipStream_t stream) {
+static inline int sigmoid_rows_per_block(int rows) { int rpb = 16; while ((rows + rpb - 1) / rpb > 2048) rpb *= 2; return rpb; }
+int ppf_sigmoid_bwd_blocks(int rows) { const int rpb = sigmoid_rows_per_block(rows); return (rows + rpb - 1) / rpb; }
+
+int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int rows, int cols, float* partial, size_t partial_bytes,
+                    hipStream_t stream) {
     PPF_CHECK_ARG(rows > 0 && cols > 0, PPF_ERR_SHAPE, "ppf_sigmoid_bwd: bad shape");
-    const int rpb = 16;
-    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, df, f, (bf16_t*)dz, dbias, rows, cols, rpb);
+    const int rpb = sigmoid_rows_per_block(rows), nblk = (rows + rpb - 1) / rpb;
+    PPF_CHECK_ARG(partial == nullptr || partial_bytes >= (size_t)nblk * cols * sizeof(float), PPF_ERR_ARG, "ppf_sigmoid_bwd: partial buffer too small");
+    if (!dbias) partial = nullptr;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk), dim3(256), 0, stream, df, f, (bf16_t*)dz, dbias, partial, rows, cols, rpb);
+    if (partial) hipLaunchKernelGGL(sigmoid_bias_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, partial, dbias, nblk, cols);
     PPF_LAUNCH_CHECK();
     return 0;
 }
@@ -190,8 +312,98 @@ int ppf_adamw_step(float* p, const float* g, float* m, float* v, float* ema, voi
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
-    a.ema_decay = ema_decay; a.grad_scale = grad_scale;
+    a.ema_decay = ema_decay; a.grad_scale = grad_scale; a.hyper = nullptr;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same step with lr / weight decay / bias corrections / gradient scale read from device memory (`hyper`, 20 floats, layout
+// above): nothing step-dependent is baked into the launch, so the call can be captured in a HIP graph and replayed.
+int ppf_adamw_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
+                       const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
+                       hipStream_t stream) {
+    PPF_CHECK_ARG(n > 0 && (n % 4) == 0 && nseg >= 1 && nseg <= MAX_SEGS && hyper, PPF_ERR_ARG, "ppf_adamw_step_dev: bad arguments");
+    AdamParams a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.p16 = (bf16_t*)p16; a.n = n; a.nseg = nseg;
+    for (int s = 0; s < MAX_SEGS; ++s) { a.seg[s].begin = a.seg[s].end = 0; a.seg[s].lr = a.seg[s].wd = 0.f; }
+    for (int s = 0; s < nseg; ++s) {
+        PPF_CHECK_ARG(seg_bounds[s] % 4 == 0 && seg_bounds[s + 1] >= seg_bounds[s], PPF_ERR_ALIGN, "ppf_adamw_step_dev: segment bounds must be multiples of 4");
+        a.seg[s].begin = seg_bounds[s]; a.seg[s].end = seg_bounds[s + 1];
+    }
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc1 = a.bc2_sqrt = 1.f; a.ema_decay = ema_decay; a.grad_scale = 1.f; a.hyper = hyper;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// hyper[0..n) <- host_vals[0..n): the values travel as kernel arguments (read from host memory NOW), so the host may run any
+// number of steps ahead of the device -- an asynchronous copy from a reused pinned buffer would read whatever the buffer holds later.
+int ppf_hyper_set(float* hyper, const float* host_vals, int n, hipStream_t stream) {
+    PPF_CHECK_ARG(hyper && host_vals && n >= 1 && n <= 20, PPF_ERR_ARG, "ppf_hyper_set: bad arguments");
+    HyperVals h;
+    for (int i = 0; i < 20; ++i) h.v[i] = i < n ? host_vals[i] : 0.f;
+    h.n = n;
+    hipLaunchKernelGGL(hyper_set_kernel, dim3(1), dim3(64), 0, stream, hyper, h);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_clip_grad_blocks(void) { return 512; }
+
+int ppf_clip_grad_scale(const float* g, int64_t n, float max_norm, float pre_scale, float* partial, float* hyper, float* norm_out,
+                        hipStream_t stream) {
+    PPF_CHECK_ARG(n > 0 && (n % 4) == 0 && max_norm > 0.f && partial && hyper, PPF_ERR_ARG, "ppf_clip_grad_scale: bad arguments");
+    const int nblk = ppf_clip_grad_blocks();
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, stream, g, n / 4, partial);
+    hipLaunchKernelGGL(clip_finish_kernel, dim3(1), dim3(256), 0, stream, partial, nblk, max_norm, pre_scale, hyper, norm_out);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_droppath_scales(float* out, const float* keep, int nslot, int B, uint64_t seed, void* state_u64, hipStream_t stream) {
+    PPF_CHECK_ARG(nslot > 0 && B > 0 && out && keep && state_u64, PPF_ERR_ARG, "ppf_droppath_scales: bad arguments");
+    hipLaunchKernelGGL(droppath_kernel, dim3(1), dim3(256), 0, stream, out, keep, nslot, B, seed, (unsigned long long*)state_u64);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_reserved_rows_map(const int* idx, int* rows, int B, int k, int N, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && k > 0 && N > k, PPF_ERR_SHAPE, "ppf_reserved_rows_map: bad shape B=%d k=%d N=%d", B, k, N);
+    hipLaunchKernelGGL(rows_map_kernel, dim3((B * (k + 1) + 255) / 256), dim3(256), 0, stream, idx, rows, B, k, N);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_gather_rows(const void* src, const int* rows, void* dst, int nrows, int row_bytes, hipStream_t stream) {
+    PPF_CHECK_ARG(nrows > 0 && row_bytes > 0 && row_bytes % 16 == 0, PPF_ERR_ALIGN, "ppf_gather_rows: row_bytes=%d must be a positive multiple of 16", row_bytes);
+    hipLaunchKernelGGL(move_rows_kernel, dim3(grid_for((int64_t)nrows * (row_bytes / 16))), dim3(256), 0, stream, (const uint4*)src, rows, (uint4*)dst,
+                       nrows, row_bytes / 16, 0);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst (nrows_dst rows) = 0 everywhere except dst[rows[r]] = src[r]
+int ppf_scatter_rows(const void* src, const int* rows, void* dst, int nrows_src, int nrows_dst, int row_bytes, hipStream_t stream) {
+    PPF_CHECK_ARG(nrows_src > 0 && nrows_dst >= nrows_src && row_bytes > 0 && row_bytes % 16 == 0, PPF_ERR_ALIGN, "ppf_scatter_rows: bad arguments");
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)nrows_dst * row_bytes, stream);
+    if (e != hipSuccess) { ppf_set_error("ppf_scatter_rows: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(move_rows_kernel, dim3(grid_for((int64_t)nrows_src * (row_bytes / 16))), dim3(256), 0, stream, (const uint4*)src, rows, (uint4*)dst,
+                       nrows_src, row_bytes / 16, 1);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_memset_zero(void* ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, stream);
+    if (e != hipSuccess) { ppf_set_error("ppf_memset_zero: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int ppf_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, hipStream_t stream) {
+    PPF_CHECK_ARG(n > 0 && x && scalar_dev && out, PPF_ERR_ARG, "ppf_scale_by_scalar: bad arguments");
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, scalar_dev, out, n);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -432,7 +432,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Launch probe (bench.py's roofline leg): HIP events on the launch stream around the split-K wgrad kernel itself -- not its
 // ordered reduce -- so that the live average agrees with rocprofv3's per-kernel average.
-struct Probe { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0.0, bytes = 0.0; };
+// Events come from a pool that is reused from one probe session to the next (nothing is created or destroyed per launch once
+// the pool has grown); when the step is captured with the probe on, the records become event-record nodes that every replay
+// re-records, so a read after the timed region returns the last replay's launch durations.
+struct Probe {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+    double flops = 0.0, bytes = 0.0;
+    std::pair<hipEvent_t, hipEvent_t> acquire() {
+        if (used == pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            pool.emplace_back(a, b);
+        }
+        return pool[used++];
+    }
+};
 Probe g_probe;
 
 int pick_splitk(int M, int N, int K) {
@@ -531,12 +547,11 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                 p.cs_parts = big ? 4 : 1;
                 p.nsplit = ns;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (g_probe.on) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, stream); }
+                if (g_probe.on) { auto ev = g_probe.acquire(); e0 = ev.first; e1 = ev.second; (void)hipEventRecord(e0, stream); }
                 int rc = deep ? launch_tt_deep(p, stream) : big ? launch_nt256_wgrad(p, stream) : launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
                 if (g_probe.on) {
                     (void)hipEventRecord(e1, stream);
-                    g_probe.ev.emplace_back(e0, e1);
                     g_probe.flops += 2.0 * M * N * (double)K;
                     g_probe.bytes += 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N;
                 }
@@ -554,19 +569,22 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     return PPF_ERR_ARG;
 }
 
-// Roofline probe of the weight-gradient kernel (epi 6 with a workspace).  enable = 1 clears and starts recording, 0 stops.
+// Roofline probe of the weight-gradient kernel (epi 6 with a workspace).  enable = 1 clears the counters and starts recording
+// (pooled events are reused), 0 stops, 2 stops and destroys the event pool (only when no captured graph references it any more).
 int ppf_gemm_probe(int enable) {
-    if (enable) {
-        for (auto& e : g_probe.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-        g_probe.ev.clear(); g_probe.flops = 0.0; g_probe.bytes = 0.0;
+    if (enable == 1) { g_probe.used = 0; g_probe.flops = 0.0; g_probe.bytes = 0.0; }
+    if (enable == 2) {
+        for (auto& e : g_probe.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        g_probe.pool.clear(); g_probe.used = 0;
     }
-    g_probe.on = enable != 0;
+    g_probe.on = enable == 1;
     return 0;
 }
 // Synchronises the recorded events: total kernel milliseconds, launches, algorithmic flops and bytes since ppf_gemm_probe(1).
 int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, double* bytes) {
     double ms = 0.0;
-    for (auto& e : g_probe.ev) {
+    for (size_t i = 0; i < g_probe.used; ++i) {
+        auto& e = g_probe.pool[i];
         float t = 0.f;
         hipError_t rc = hipEventSynchronize(e.second);
         if (rc == hipSuccess) rc = hipEventElapsedTime(&t, e.first, e.second);
@@ -574,7 +592,7 @@ int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, doub
         ms += t;
     }
     if (ms_total) *ms_total = ms;
-    if (launches) *launches = (int64_t)g_probe.ev.size();
+    if (launches) *launches = (int64_t)g_probe.used;
     if (flops) *flops = g_probe.flops;
     if (bytes) *bytes = g_probe.bytes;
     return 0;

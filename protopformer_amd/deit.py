@@ -96,7 +96,8 @@ class MyVisionTransformer(nn.Module):
         store = self._store()
         x = torch.cat([cls_embed, x_embed], dim=1).contiguous()
         (layer, k), = reserve_layer_nums
-        x_out, cls_attn, idx, _ = deit_blocks_fwd(self, store, x, layer, k, dp=None, save=False)
+        # all 1+Np tokens come back, as in the reference (callers gather x[:, 1:] with indices up to Np-1, protopformer.py:156-162)
+        x_out, cls_attn, idx, _ = deit_blocks_fwd(self, store, x, layer, k, dp=None, save=False, compact=False)
         B, N, D = x_out.shape
         y, _, _ = ops.layernorm_fwd(x_out.reshape(B * N, D), self.norm.weight, self.norm.bias, LN_EPS)
         return y.float().reshape(B, N, D), (cls_attn, None)

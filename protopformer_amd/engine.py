@@ -1,11 +1,16 @@
-"""Train-step loop of the hot path (tools/engine_proto.py:41-81; optimizer groups tools/create_optimizer.py:27-39).
+"""Train-step loop of the hot path (tools/engine_proto.py:41-81; optimizer groups tools/create_optimizer.py:27-39;
+schedule tools/create_scheduler.py:20-32; checkpoint layout main.py:393-407, 436-471).
 
-* FlatAdamW  : torch.optim.AdamW semantics as ONE fused HIP kernel over the flat (p, g, m, v[, ema]) buffers that also
-               re-emits the bf16 weight shadow; param_groups expose lr / weight_decay so schedulers work unchanged.
-* GradSync   : data-parallel gradient exchange = chunked RCCL all-reduce of the flat gradient buffer on a side
-               stream, launched as soon as a chunk's layers have finished their backward (overlap), averaged by
-               folding 1/world into the optimizer kernel.
-* train_one_step / train_one_epoch : the reference's step body (forward, CE + PPC, backward, step, EMA).
+* FlatAdamW          : torch.optim.AdamW semantics as ONE fused HIP kernel over the flat (p, g, m, v[, ema]) buffers that also
+                       re-emits the bf16 weight shadow; param_groups expose lr / weight_decay so schedulers work unchanged;
+                       state_dict()/load_state_dict() speak torch.optim.AdamW's per-parameter format (reference --resume files).
+* CosineLRScheduler  : the timm scheduler the reference builds (warm-up + cosine, stepped per epoch).
+* GradSync           : data-parallel gradient exchange = chunked RCCL all-reduce of the flat gradient buffer on a side
+                       stream, launched as soon as a chunk's layers have finished their backward (overlap), averaged by
+                       folding 1/world into the optimizer kernel; replicas are made identical by a rank-0 broadcast.
+* train_one_step / GraphedTrainStep / train_one_epoch : the reference's step body (forward, CE + PPC, backward, clip, step,
+                       EMA), eagerly or as one captured HIP graph that is replayed per step.
+* save_checkpoint / load_checkpoint : the reference's checkpoint dict {model, optimizer, lr_scheduler, epoch, model_ema}.
 """
 import math
 import os
@@ -14,14 +19,27 @@ import sys
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, ops
 from .protopformer import CrossEntropyLoss
 
 DEFAULT_LRS = {"features": 1e-4, "add_on_layers": 3e-3, "prototype_vectors": 3e-3}       # main.py:64-66
 
+# device-resident step state of ppf_adamw_step_dev (include/ppf_hip.h)
+_HY_LR, _HY_WD, _HY_BC1, _HY_BC2, _HY_GSCALE, _HY_CLIP, _HY_N = 0, 8, 16, 17, 18, 19, 20
+
+
+def _unwrap(model):
+    """Data parallelism here is GradSync on the flat gradient buffer; a DistributedDataParallel wrapper would see every
+    parameter as unused (the kernels write gradients straight into the flat buffer) and silently skip the reduction."""
+    if isinstance(model, (torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)):
+        raise RuntimeError("protopformer_amd: do not wrap the model in DistributedDataParallel / DataParallel -- gradients are written into "
+                           "a flat buffer by the HIP kernels and exchanged by engine.GradSync (pass grad_sync=make_grad_sync(model, optimizer))")
+    return model
+
 
 class FlatAdamW:
     def __init__(self, ppnet, joint_optimizer_lrs=None, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, ema_decay=None):
+        ppnet = _unwrap(ppnet)
         lrs = dict(DEFAULT_LRS if joint_optimizer_lrs is None else joint_optimizer_lrs)
         self.ppnet = ppnet
         self.store = ppnet.flat_store()
@@ -30,49 +48,209 @@ class FlatAdamW:
         wds = {"features": 1e-3, "add_on_layers": 1e-3, "prototype_vectors": weight_decay, "prototype_vectors_global": weight_decay}
         lr_of = {"features": lrs["features"], "add_on_layers": lrs["add_on_layers"], "prototype_vectors": lrs["prototype_vectors"],
                  "prototype_vectors_global": lrs["prototype_vectors"]}
-        self.param_groups = [dict(name=n, lr=lr_of[n], weight_decay=wds[n], begin=b, end=e, initial_lr=lr_of[n]) for n, b, e in st.segments]
         self.betas, self.eps = betas, eps
-        self.exp_avg = torch.zeros_like(st.params)
-        self.exp_avg_sq = torch.zeros_like(st.params)
+        self.param_groups = []
+        for n, b, e in st.segments:
+            params = [p for _, p, o, _ in st.entries if b <= o < e]
+            self.param_groups.append(dict(name=n, lr=lr_of[n], weight_decay=wds[n], begin=b, end=e, initial_lr=lr_of[n], params=params,
+                                          betas=betas, eps=eps, amsgrad=False))
+        self.exp_avg = ops.zeros(st.params.shape, torch.float32, st.device)
+        self.exp_avg_sq = ops.zeros(st.params.shape, torch.float32, st.device)
         self.ema = st.params.clone() if ema_decay is not None else None
         self.ema_decay = 0.0 if ema_decay is None else float(ema_decay)
         self.step_count = 0
         self.grad_scale = 1.0
         self._bounds = torch.tensor([g["begin"] for g in self.param_groups] + [self.param_groups[-1]["end"]], dtype=torch.int64)
-        self._lr = torch.zeros(len(self.param_groups), dtype=torch.float32)
-        self._wd = torch.zeros(len(self.param_groups), dtype=torch.float32)
+        # step-dependent scalars live in device memory (refreshed from this host mirror before every step), so that the
+        # optimizer launch itself is step-independent and a captured graph of the step can be replayed
+        self._hyper_host = torch.zeros(_HY_N, dtype=torch.float32)
+        self._hyper_host[_HY_CLIP] = 1.0
+        self._hyper = torch.empty(_HY_N, dtype=torch.float32, device=st.device)
+        _lib.call("ppf_hyper_set", self._hyper, self._hyper_host.data_ptr(), _HY_N)
+        self._clip_partial = None
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=st.device)
+
+    # ------------------------------------------------------------------ consistency with the model's flat store
+    def _check_store(self):
+        if self.ppnet.flat_store() is not self.store:
+            raise RuntimeError("FlatAdamW: the model's flat parameter store was rebuilt after this optimizer was created (model.to()/"
+                               ".cuda()/.float() re-materialised the parameters); create the optimizer after moving the model")
 
     def zero_grad(self, set_to_none=False):
+        self._check_store()
         self.store.zero_grad()
 
-    def step(self):
-        st = self.store
+    # ------------------------------------------------------------------ the step
+    def refresh_hyper(self):
+        """Advance the step count and push lr / weight decay / bias corrections / gradient scale to device memory (a one-wave kernel
+        that carries the values as launch arguments).  GraphedTrainStep calls this right before each replay."""
         self.step_count += 1
+        h = self._hyper_host
         for i, g in enumerate(self.param_groups):
-            self._lr[i] = g["lr"]
-            self._wd[i] = g["weight_decay"]
-        _lib.call("ppf_adamw_step", st.params, st.grads, self.exp_avg, self.exp_avg_sq, self.ema, st.bf16, st.total, len(self.param_groups),
-                  self._bounds.data_ptr(), self._lr.data_ptr(), self._wd.data_ptr(), self.betas[0], self.betas[1], self.eps,
-                  self.step_count, self.ema_decay, float(self.grad_scale))
+            h[_HY_LR + i] = g["lr"]
+            h[_HY_WD + i] = g["weight_decay"]
+        h[_HY_BC1] = 1.0 - self.betas[0] ** self.step_count
+        h[_HY_BC2] = math.sqrt(1.0 - self.betas[1] ** self.step_count)
+        h[_HY_GSCALE] = float(self.grad_scale)
+        _lib.call("ppf_hyper_set", self._hyper, h.data_ptr(), _HY_CLIP)
+
+    def clip_grad_norm(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ over all trainable gradients (timm dispatch_clip_grad mode 'norm'), folded into the
+        optimizer kernel as a coefficient in device memory; self.grad_norm holds the (averaged-gradient) norm."""
+        if self._clip_partial is None:
+            self._clip_partial = torch.empty(_lib.lib().ppf_clip_grad_blocks(), dtype=torch.float32, device=self.store.device)
+        _lib.call("ppf_clip_grad_scale", self.store.grads, self.store.total, float(max_norm), float(self.grad_scale), self._clip_partial,
+                  self._hyper, self.grad_norm)
+
+    def launch_update(self):
+        st = self.store
+        _lib.call("ppf_adamw_step_dev", st.params, st.grads, self.exp_avg, self.exp_avg_sq, self.ema, st.bf16, st.total, len(self.param_groups),
+                  self._bounds.data_ptr(), self._hyper, self.betas[0], self.betas[1], self.eps, self.ema_decay)
         st.bf16_fresh = True                      # the kernel re-emitted the bf16 shadow
 
+    def step(self):
+        self._check_store()
+        self.refresh_hyper()
+        self.launch_update()
+
+    # ------------------------------------------------------------------ checkpoint format: torch.optim.AdamW's
     def state_dict(self):
-        return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_count, ema=self.ema,
-                    param_groups=[{k: v for k, v in g.items()} for g in self.param_groups])
+        """The dict torch.optim.AdamW.state_dict() would give for the reference's four groups (create_optimizer.py:31-39):
+        per-parameter {'step', 'exp_avg', 'exp_avg_sq'} keyed by the parameter's index, and the groups with index lists."""
+        state, groups, i = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for _, p, o, n in self.store.entries:
+                if not (g["begin"] <= o < g["end"]):
+                    continue
+                if self.step_count > 0:
+                    state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.exp_avg[o:o + n].view(p.shape).clone(),
+                                    exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape).clone())
+                ids.append(i)
+                i += 1
+            groups.append(dict(lr=g["lr"], betas=tuple(self.betas), eps=self.eps, weight_decay=g["weight_decay"], amsgrad=False,
+                               initial_lr=g["initial_lr"], params=ids))
+        return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_count = sd["step"]
-        if self.ema is not None and sd.get("ema") is not None:
-            self.ema.copy_(sd["ema"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
+        if "exp_avg" in sd and "state" not in sd:           # round-1 flat format
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_count = int(sd["step"])
+            if self.ema is not None and sd.get("ema") is not None:
+                self.ema.copy_(sd["ema"])
+            for g, s in zip(self.param_groups, sd["param_groups"]):
+                g.update(lr=s["lr"], weight_decay=s["weight_decay"])
+            return
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError(f"optimizer checkpoint has {len(groups)} param groups, expected {len(self.param_groups)}")
+        steps = set()
+        i = 0
+        for g, s in zip(self.param_groups, groups):
+            mine = [(p, o, n) for _, p, o, n in self.store.entries if g["begin"] <= o < g["end"]]
+            if len(mine) != len(s["params"]):
+                raise ValueError(f"group {g['name']}: checkpoint has {len(s['params'])} parameters, model has {len(mine)}")
+            for (p, o, n), pid in zip(mine, s["params"]):
+                ent = sd["state"].get(pid, sd["state"].get(str(pid)))
+                if ent is None:
+                    self.exp_avg[o:o + n].zero_(); self.exp_avg_sq[o:o + n].zero_()
+                    steps.add(0)
+                    continue
+                if tuple(ent["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {pid}: shape {tuple(ent['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+                self.exp_avg[o:o + n].copy_(ent["exp_avg"].reshape(-1)); self.exp_avg_sq[o:o + n].copy_(ent["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(ent["step"])))
+                i += 1
             g.update(lr=s["lr"], weight_decay=s["weight_decay"])
+            if "initial_lr" in s:
+                g["initial_lr"] = s["initial_lr"]
+        if len(steps) > 1:
+            raise ValueError(f"the fused kernel keeps one step count for all parameters; checkpoint has {sorted(steps)}")
+        self.step_count = steps.pop() if steps else 0
 
     def ema_state_dict(self):
-        """EMA weights under the model's state-dict keys (trainable tensors only)."""
-        out = {}
-        for name, p, o, n in self.store.entries:
-            out[name] = self.ema[o:o + n].view(p.shape).clone()
+        """timm get_state_dict(model_ema) (main.py:444): the EMA weights under the model's state-dict keys; frozen entries
+        (ones, last_layer*.weight) are copied from the model -- they never change, so their average equals them."""
+        out = {k: v.detach().clone() for k, v in self.ppnet.state_dict().items()}
+        if self.ema is not None:
+            for name, p, o, n in self.store.entries:
+                out[name] = self.ema[o:o + n].view(p.shape).clone()
         return out
+
+    def load_ema_state_dict(self, sd):
+        """utils._load_checkpoint_for_ema (main.py:405)."""
+        if self.ema is None:
+            return
+        for name, p, o, n in self.store.entries:
+            if name in sd:
+                self.ema[o:o + n].copy_(sd[name].reshape(-1))
+
+
+class CosineLRScheduler:
+    """timm.scheduler.CosineLRScheduler as tools/create_scheduler.py:20-32 configures it (t_in_epochs, cycle_limit 1, no noise,
+    warmup_prefix False, cycle_mul 1, cycle_decay 1): written from the timm 0.5.4 API -- timm is not vendored in the reference
+    and not installed here, so this boundary is unpinned (tests pin it to the closed-form table).
+
+        t <  warmup_t : lr_g = warmup_lr_init + t * (base_g - warmup_lr_init) / warmup_t
+        t >= warmup_t : lr_g = lr_min + 0.5 * (base_g - lr_min) * (1 + cos(pi * t / t_initial))      for t < t_initial
+                        lr_g = lr_min                                                                 afterwards (cool-down)
+
+    base_g is each group's `initial_lr`.  Construction sets every group to warmup_lr_init; main.py:434 calls step(epoch) AFTER
+    epoch `epoch` has trained (so epochs 0 and 1 both run at warmup_lr_init -- the reference's off-by-one, reproduced by
+    keeping the same call)."""
+
+    def __init__(self, optimizer, t_initial, lr_min=0.0, warmup_lr_init=0.0, warmup_t=0, cycle_limit=1, t_in_epochs=True, **_unused):
+        self.optimizer = optimizer
+        self.t_initial, self.lr_min, self.warmup_lr_init, self.warmup_t = int(t_initial), float(lr_min), float(warmup_lr_init), int(warmup_t)
+        self.cycle_limit, self.t_in_epochs = int(cycle_limit), bool(t_in_epochs)
+        for g in optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        self.base_values = [g["initial_lr"] for g in optimizer.param_groups]
+        if self.warmup_t:
+            self.warmup_steps = [(v - self.warmup_lr_init) / self.warmup_t for v in self.base_values]
+            self._update([self.warmup_lr_init] * len(self.base_values))
+        else:
+            self.warmup_steps = [1.0 for _ in self.base_values]
+
+    def _get_lr(self, t):
+        if t < self.warmup_t:
+            return [self.warmup_lr_init + t * s for s in self.warmup_steps]
+        i = t // self.t_initial
+        t_curr = t - self.t_initial * i
+        if i < self.cycle_limit:
+            return [self.lr_min + 0.5 * (v - self.lr_min) * (1.0 + math.cos(math.pi * t_curr / self.t_initial)) for v in self.base_values]
+        return [self.lr_min for _ in self.base_values]
+
+    def get_cycle_length(self, cycles=0):
+        return self.t_initial * max(1, cycles or self.cycle_limit)
+
+    def _update(self, values):
+        for g, v in zip(self.optimizer.param_groups, values):
+            g["lr"] = v
+
+    def step(self, epoch, metric=None):
+        if self.t_in_epochs:
+            self._update(self._get_lr(epoch))
+
+    def step_update(self, num_updates, metric=None):
+        if not self.t_in_epochs:
+            self._update(self._get_lr(num_updates))
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
+
+
+def create_scheduler(args, optimizer):
+    """tools/create_scheduler.py:4-36 for --sched cosine (the only schedule scripts/train_*.sh use).  Returns (scheduler, num_epochs)."""
+    if getattr(args, "sched", "cosine") != "cosine":
+        raise NotImplementedError("only the cosine schedule of scripts/train_cub.sh is on the path")
+    if getattr(args, "lr_noise", None) is not None:
+        raise NotImplementedError("lr noise is off in every reference script")
+    s = CosineLRScheduler(optimizer, t_initial=args.epochs, lr_min=getattr(args, "min_lr", 1e-5), warmup_lr_init=getattr(args, "warmup_lr", 1e-6),
+                          warmup_t=getattr(args, "warmup_epochs", 5), cycle_limit=getattr(args, "lr_cycle_limit", 1), t_in_epochs=True)
+    return s, s.get_cycle_length() + getattr(args, "cooldown_epochs", 10)
 
 
 class GradSync:
@@ -123,8 +301,31 @@ class GradSync:
         return 1.0 / self.world
 
 
-def make_grad_sync(ppnet, n_chunks=4):
-    """Chunk the flat gradient in backward-completion order: [heads+norm | late blocks | ... | early blocks+embedding]."""
+def broadcast_replica_state(ppnet, optimizer=None, src=0):
+    """What DistributedDataParallel does at wrap time (main.py:370): every rank starts from rank `src`'s parameters and buffers
+    -- the reference seeds each rank differently (main.py:254 seed + rank), so without this the replicas would apply averaged
+    gradients to diverging weights.  Also aligns the optimizer moments / EMA copy."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    st = ppnet.flat_store()
+    with torch.no_grad():
+        dist.broadcast(st.params, src)
+        for name, t in ppnet.state_dict().items():
+            if not any(t.data_ptr() == p.data_ptr() for _, p, _, _ in st.entries):          # frozen tensors: ones, last_layer*.weight
+                dist.broadcast(t, src)
+        if optimizer is not None:
+            dist.broadcast(optimizer.exp_avg, src)
+            dist.broadcast(optimizer.exp_avg_sq, src)
+            if optimizer.ema is not None:
+                optimizer.ema.copy_(st.params)
+    st.invalidate()
+
+
+def make_grad_sync(ppnet, optimizer=None, n_chunks=4):
+    """Chunk the flat gradient in backward-completion order: [heads+norm | late blocks | ... | early blocks+embedding], after
+    making the replicas identical (rank-0 broadcast of parameters, frozen tensors and optimizer state)."""
+    ppnet = _unwrap(ppnet)
+    broadcast_replica_state(ppnet, optimizer)
     st = ppnet.flat_store()
     block_offsets = []
     for name, p, o, n in st.entries:
@@ -147,9 +348,8 @@ def make_grad_sync(ppnet, n_chunks=4):
     return sync
 
 
-def train_one_step(model, criterion, samples, targets, optimizer, epoch=20, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True,
-                   grad_sync=None, check_finite=False):
-    """One iteration of tools/engine_proto.py:41-81 (without logging). Returns the detached loss tensors."""
+def _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss, grad_sync, check_finite,
+                      max_norm):
     outputs, auxi = model(samples)
     loss = criterion(outputs, targets)
     cov = mean = None
@@ -166,21 +366,92 @@ def train_one_step(model, criterion, samples, targets, optimizer, epoch=20, ppc_
     model._grad_sync = None
     if grad_sync is not None:
         optimizer.grad_scale = grad_sync.finish()
+    if max_norm is not None:                                      # loss_scaler(..., clip_grad=max_norm) (engine_proto.py:74-76)
+        optimizer.clip_grad_norm(max_norm)
+    return loss, cov, mean
+
+
+def train_one_step(model, criterion, samples, targets, optimizer, epoch=20, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True,
+                   grad_sync=None, check_finite=False, max_norm=None):
+    """One iteration of tools/engine_proto.py:41-81 (without logging). Returns the detached loss tensors.
+    The reference's NativeScaler (fp16 loss scaling) has no role here: the kernels accumulate in fp32 from bf16 operands."""
+    _unwrap(model)
+    loss, cov, mean = _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss,
+                                        grad_sync, check_finite, max_norm)
     optimizer.step()
     return loss.detach(), (cov.detach() if cov is not None else None), (mean.detach() if mean is not None else None)
 
 
-def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, args=None, grad_sync=None, log_every=30, logger=print):
-    """Epoch loop with the reference's signature shape (engine_proto.py:24-113); data_loader yields (samples, targets)."""
+class GraphedTrainStep:
+    """The same step as ONE captured HIP graph (both compute streams and, under data parallelism, the RCCL collectives included).
+
+    ~400 kernel launches per step cost 12-19 ms of host time through ctypes; a replay costs one launch.  Everything that changes from
+    step to step lives in device memory: the batch (static input buffers), the AdamW step state (FlatAdamW.refresh_hyper copies
+    lr / weight decay / bias corrections before each replay) and the DropPath step counter (advanced by the kernel itself).
+    The first `warmup` calls run eagerly (they also size the split-K workspaces); the next call captures; later calls replay.
+    Outputs are the graph's static loss tensors (overwritten by the next replay)."""
+
+    def __init__(self, model, criterion, optimizer, epoch=20, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True, grad_sync=None,
+                 max_norm=None, warmup=2, adopt_inputs=False):
+        self.model, self.criterion, self.optimizer = _unwrap(model), criterion, optimizer
+        self.kw = dict(epoch=epoch, ppc_cov_coe=ppc_cov_coe, ppc_mean_coe=ppc_mean_coe, use_ppc_loss=use_ppc_loss, grad_sync=grad_sync,
+                       check_finite=False, max_norm=max_norm)
+        self.grad_sync = grad_sync
+        self.warmup = warmup
+        self.adopt_inputs = adopt_inputs          # True: the first captured batch's tensors BECOME the static buffers (resident data)
+        self.calls = 0
+        self.graph = None
+        self.static_in = None
+        self.out = None
+
+    def _capture(self, samples, targets):
+        opt = self.optimizer
+        self.static_in = (samples, targets) if self.adopt_inputs else (samples.clone(), targets.clone())
+        if self.grad_sync is not None:
+            opt.grad_scale = 1.0 / self.grad_sync.world
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss, cov, mean = _forward_backward(self.model, self.criterion, self.static_in[0], self.static_in[1], opt, **self.kw)
+            opt.launch_update()
+            self.out = (loss.detach(), cov.detach() if cov is not None else None, mean.detach() if mean is not None else None)
+
+    def __call__(self, samples, targets):
+        opt = self.optimizer
+        opt._check_store()
+        self.calls += 1
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                return train_one_step(self.model, self.criterion, samples, targets, opt, **self.kw)
+            self._capture(samples, targets)
+        if samples.data_ptr() != self.static_in[0].data_ptr():
+            self.static_in[0].copy_(samples, non_blocking=True)
+        if targets.data_ptr() != self.static_in[1].data_ptr():
+            self.static_in[1].copy_(targets, non_blocking=True)
+        opt.refresh_hyper()
+        self.graph.replay()
+        return self.out
+
+
+def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, args=None, grad_sync=None, log_every=30, logger=print,
+                    max_norm=None, step_fn=None):
+    """Epoch loop with the reference's signature shape (engine_proto.py:24-113); data_loader yields (samples, targets).
+    step_fn: a GraphedTrainStep (replayed graph) instead of the eager train_one_step."""
     model.train(True)
     use_ppc = True if args is None else bool(getattr(args, "use_ppc_loss", True))
     cov_coe = 0.1 if args is None else getattr(args, "ppc_cov_coe", 0.1)
     mean_coe = 0.5 if args is None else getattr(args, "ppc_mean_coe", 0.5)
+    if max_norm is None and args is not None:
+        max_norm = getattr(args, "clip_grad", None)
     total, n = 0.0, 0
     for it, (samples, targets) in enumerate(data_loader):
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
-        loss, _, _ = train_one_step(model, criterion, samples, targets, optimizer, epoch, cov_coe, mean_coe, use_ppc, grad_sync)
+        if step_fn is not None:
+            loss, _, _ = step_fn(samples, targets)
+        else:
+            loss, _, _ = train_one_step(model, criterion, samples, targets, optimizer, epoch, cov_coe, mean_coe, use_ppc, grad_sync,
+                                        max_norm=max_norm)
         if it % log_every == 0:
             v = float(loss)
             if not math.isfinite(v):
@@ -208,3 +479,44 @@ def evaluate(data_loader, model, device):
         correct_l += int((aux[3].argmax(1) == target).sum())
         count += images.shape[0]
     return dict(acc1=100.0 * correct / count, global_acc1=100.0 * correct_g / count, local_acc1=100.0 * correct_l / count, loss=loss_sum / count)
+
+
+# ---------------------------------------------------------------------------------------------------- checkpoint I/O
+def save_checkpoint(path, model, optimizer, lr_scheduler, epoch, args=None, master_only=True):
+    """The reference's checkpoint dict (main.py:436-447, 460-471; tools/utils.py:242-244 save_on_master):
+    {'model', 'optimizer', 'lr_scheduler', 'epoch', 'model_ema', 'args'} -- 'scaler' is omitted (no fp16 loss scaling here)."""
+    if master_only and dist.is_initialized() and dist.get_rank() != 0:
+        return
+    ck = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+          "optimizer": _to_cpu(optimizer.state_dict()),
+          "lr_scheduler": lr_scheduler.state_dict() if lr_scheduler is not None else None,
+          "epoch": int(epoch),
+          "model_ema": {k: v.cpu() for k, v in optimizer.ema_state_dict().items()} if optimizer.ema is not None else None,
+          "args": args}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(ck, path)
+
+
+def _to_cpu(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu()
+    if isinstance(x, dict):
+        return {k: _to_cpu(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_cpu(v) for v in x)
+    return x
+
+
+def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, strict=True, eval_only=False):
+    """main.py:393-407 (--resume) and main_visualize.py:289 (strict=False).  Returns the epoch to start from."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["model"] if "model" in ck else ck, strict=strict)
+    start = 0
+    if not eval_only and optimizer is not None and all(k in ck for k in ("optimizer", "lr_scheduler", "epoch")):
+        optimizer.load_state_dict(ck["optimizer"])
+        if lr_scheduler is not None and ck["lr_scheduler"] is not None:
+            lr_scheduler.load_state_dict(ck["lr_scheduler"])
+        start = ck["epoch"] + 1
+        if ck.get("model_ema") is not None:
+            optimizer.load_ema_state_dict(ck["model_ema"])
+    return start

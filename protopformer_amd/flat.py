@@ -65,14 +65,14 @@ class FlatStore:
         """The flat-gradient view of p, attached as p.grad (zeroed first if p.grad had been dropped)."""
         g = self._gviews[id(p)]
         if p.grad is None or p.grad.data_ptr() != g.data_ptr():
-            g.zero_()
+            ops.zero_(g)
             p.grad = g
         return g
 
     def attach_all_grads(self):
         """Called at the start of a backward pass: if every grad was set to None (zero_grad default), one memset."""
         if all(p.grad is None for _, p, _, _ in self.entries):
-            self.grads.zero_()
+            ops.zero_(self.grads)
             for _, p, _, _ in self.entries:
                 p.grad = self._gviews[id(p)]
         else:
@@ -80,7 +80,7 @@ class FlatStore:
                 self.grad_view(p)
 
     def zero_grad(self):
-        self.grads.zero_()
+        ops.zero_(self.grads)
         for _, p, _, _ in self.entries:
             p.grad = self._gviews[id(p)]
 

@@ -44,7 +44,9 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
     assert K == Kb, f"contraction mismatch {K} vs {Kb}"
     if out is None:
         odt = torch.float32 if epi in (EPI_F32, EPI_SIGMOID_F32, EPI_RESID, EPI_ATOMIC) else torch.bfloat16
-        out = (torch.zeros if epi == EPI_ATOMIC else torch.empty)((M, N), dtype=odt, device=a.device)
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+        if epi == EPI_ATOMIC:
+            zero_(out)
     ldaux = 0
     for t in (aux_in, aux_out):
         if t is not None:
@@ -83,7 +85,8 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, *, dres_in=None, dx_out=None, ro
     sums = (dw if dy is not None else None, db if dy is not None else None, dbias_next if cast_out is not None else None,
             dcolscale if (cast_out is not None and branch is not None) else None)
     part = None
-    if rows >= 4096 and any(t is not None for t in sums) and os.environ.get("PPF_LN_PARTIAL", "1") != "0":
+    # fixed-order two-pass column sums at every size (bit-identical from run to run); PPF_LN_PARTIAL=0 -> fp32 atomics
+    if any(t is not None for t in sums) and os.environ.get("PPF_LN_PARTIAL", "1") != "0":
         dev = (dy if dy is not None else dres_in).device
         part = torch.empty(_lib.lib().ppf_layernorm_bwd_blocks(rows) * 4 * D, dtype=torch.float32, device=dev)
     _lib.call("ppf_layernorm_bwd", dy, x, row_map, w, mean, rstd, dres_in, dx_out, dw, db, cast_out, rowscale, rows_per_group,
@@ -183,7 +186,7 @@ def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_
 def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4):
     B, Ttot, Dp = tokens.shape
     P = protos.shape[0]
-    bitmap = torch.zeros((B, T, (P + 31) // 32), dtype=torch.int32, device=tokens.device) if dtok is not None else None
+    bitmap = zeros((B, T, (P + 31) // 32), torch.int32, tokens.device) if dtok is not None else None
     _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_full, g_max, argmax, dtok,
               Ttot * Dp, dprotos, bitmap, bitmap.numel() * 4 if bitmap is not None else 0)
 
@@ -202,7 +205,7 @@ def ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh):
 
 def ppc_loss_bwd(gcov, gmean, up_cov, up_mean, label, P):
     B, ppc, T = gcov.shape
-    g_full = torch.zeros((B, P, T), dtype=torch.float32, device=gcov.device)
+    g_full = zeros((B, P, T), torch.float32, gcov.device)
     _lib.call("ppf_ppc_loss_bwd", gcov, gmean, up_cov, up_mean, label, g_full, B, P, T, ppc)
     return g_full
 
@@ -241,8 +244,59 @@ def topk_sorted(scores, k):
 def sigmoid_bwd(df, f, dbias):
     rows, cols = f.shape
     dz = torch.empty((rows, cols), dtype=torch.bfloat16, device=f.device)
-    _lib.call("ppf_sigmoid_bwd", df, f, dz, dbias, rows, cols)
+    part = torch.empty(_lib.lib().ppf_sigmoid_bwd_blocks(rows) * cols, dtype=torch.float32, device=f.device) if dbias is not None else None
+    _lib.call("ppf_sigmoid_bwd", df, f, dz, dbias, rows, cols, part, part.numel() * 4 if part is not None else 0)
     return dz
+
+
+# ------------------------------------------------------------------------------------------------ plumbing kernels
+def zeros(shape, dtype, device):
+    """torch.zeros on the library's own memset node (keeps a captured step free of ATen fill kernels)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    _lib.call("ppf_memset_zero", t, t.numel() * t.element_size())
+    return t
+
+
+def zero_(t):
+    _lib.call("ppf_memset_zero", t, t.numel() * t.element_size())
+    return t
+
+
+def reserved_rows_map(idx, N):
+    """Flat source rows [B*(1+k)] int32 of [cls, 1+idx...] in the [B*N] token matrix."""
+    B, k = idx.shape
+    rows = torch.empty(B * (k + 1), dtype=torch.int32, device=idx.device)
+    _lib.call("ppf_reserved_rows_map", idx, rows, B, k, N)
+    return rows
+
+
+def gather_rows(src, rows):
+    """dst[r] = src[rows[r]] for a 2-D contiguous src."""
+    _chk(src)
+    dst = torch.empty((rows.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
+    _lib.call("ppf_gather_rows", src, rows, dst, rows.numel(), src.shape[1] * src.element_size())
+    return dst
+
+
+def scatter_rows(src, rows, nrows_dst):
+    """zeros(nrows_dst, D) with dst[rows[r]] = src[r]."""
+    _chk(src)
+    dst = torch.empty((nrows_dst, src.shape[1]), dtype=src.dtype, device=src.device)
+    _lib.call("ppf_scatter_rows", src, rows, dst, src.shape[0], nrows_dst, src.shape[1] * src.element_size())
+    return dst
+
+
+def droppath_draw(out, keep, seed, state):
+    """out [nslot, B] <- floor(keep + U)/keep; advances the device-resident step counter `state` (int64[1])."""
+    nslot, B = out.shape
+    _lib.call("ppf_droppath_scales", out, keep, nslot, B, int(seed) & 0xFFFFFFFFFFFFFFFF, state)
+    return out
+
+
+def scale_by_scalar(x, scalar):
+    out = torch.empty_like(x)
+    _lib.call("ppf_scale_by_scalar", x, scalar, out, x.numel())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ CaiT
@@ -312,3 +366,52 @@ def merge3_cast(a, b, cq, N1):
     out = torch.empty((rows, D), dtype=torch.bfloat16, device=a.device)
     _lib.call("ppf_merge3_cast", a, b, cq, out, rows, D, N1)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ fp32 verification path
+def linear_f32(x, w, bias=None, kind=0, res=None, rowscale=None, rows_per_group=1, colscale=None):
+    """fp32 y = epilogue(x W^T + b) through ppf_sgemm (fp32 FMA) + ppf_epilogue_f32.  x [M,K] (row stride may exceed K), w [N,K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    w2 = w.reshape(N, -1)
+    assert w2.shape[1] == K and w2.is_contiguous() and x.stride(1) == 1
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, 16 * M * N * 4) if M * N <= (1 << 22) else None
+    _lib.call("ppf_sgemm", x, w2, out, M, N, K, x.stride(0), 1, K, 1, N, 1.0, 0.0, ws, ws.numel() // 4 if ws is not None else 0)
+    _lib.call("ppf_epilogue_f32", out, bias, kind, res, rowscale, rows_per_group, colscale, M, N)
+    return out
+
+
+def layernorm_fwd_f32(x, w, b, eps=1e-6, row_map=None):
+    D = x.shape[-1]
+    rows = row_map.numel() if row_map is not None else x.numel() // D
+    y = torch.empty((rows, D), dtype=torch.float32, device=x.device)
+    _lib.call("ppf_layernorm_fwd_f32", x, row_map, w, b, y, rows, D, float(eps))
+    return y
+
+
+def im2col_patch_f32(img, patch):
+    B, C, H, W = img.shape
+    cols = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), dtype=torch.float32, device=img.device)
+    _lib.call("ppf_im2col_patch_f32", img, cols, B, C, H, W, patch)
+    return cols
+
+
+def attn_fwd_f32(qkv, B, H, N, D, policy=None, self_keep=True, headmean=None, eps_n=0):
+    out = torch.empty((B * N, D), dtype=torch.float32, device=qkv.device)
+    NP = headmean.shape[-1] if headmean is not None else 0
+    _lib.call("ppf_attn_fwd_f32", qkv, out, policy, headmean, NP, B, H, N, D, int(self_keep), int(eps_n))
+    return out
+
+
+def th_attn_fwd_f32(qkv, wl, bl, ww, bw, B, H, N, D, headmean):
+    out = torch.empty((B * N, D), dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_th_attn_fwd_f32", qkv, wl, bl, ww, bw, out, headmean, headmean.shape[-1], B, H, N, D)
+    return out
+
+
+def class_attn_fwd_f32(q, k, v, policy, B, H, N1, D):
+    out = torch.empty((B, D), dtype=torch.float32, device=q.device)
+    attn_mean = torch.empty((B, N1), dtype=torch.float32, device=q.device)
+    _lib.call("ppf_class_attn_fwd_f32", q, k, v, policy, attn_mean, out, B, H, N1, D)
+    return out, attn_mean

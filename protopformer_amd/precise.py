@@ -1,0 +1,107 @@
+"""fp32 verification mode of the backbone (forward only): the same call sequence as backbone.py / cait.py with every operand and
+intermediate in fp32 (csrc/precise.hip + ppf_sgemm), the masked full-length blocks of the reference after the token reservation
+(no compaction), fp32 master weights.  Enabled by ``PPNet.precise = True`` or ``PPF_PRECISE=1`` under ``torch.no_grad()``.
+
+Purpose: the bf16 product path carries ~4e-3 of operand rounding per GEMM, so end to end it can only be gated at a few 1e-3; this
+mode holds the *whole* forward / loss to the north-star 1e-3 rel against the reference-generated fixtures
+(tests/test_gpu_precise.py), which separates "bf16 rounding" from "kernel / orchestration bug" (rollout, reservation, prototype
+layer, PPC and CE kernels are shared with the product path).  It is never on the measured path.
+Reference lines: deit:172-240, cait:303-345, protopformer.py:141-173."""
+import torch
+
+from . import ops
+from .backbone import LN_EPS, _dp
+
+
+def _mlp(blk, x1, N, s2, colscale=None):
+    n2 = ops.layernorm_fwd_f32(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+    h = ops.linear_f32(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, kind=1)
+    return ops.linear_f32(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, kind=3, res=x1, rowscale=s2, rows_per_group=N, colscale=colscale)
+
+
+def _embed(feats, img, lead):
+    pe = feats.patch_embed
+    B, D, Np = img.shape[0], feats.embed_dim, pe.num_patches
+    cols = ops.im2col_patch_f32(img.contiguous().float(), pe.patch_size)
+    tok = ops.linear_f32(cols, pe.proj.weight, pe.proj.bias)
+    return ops.assemble_tokens(tok, feats.cls_token, feats.pos_embed, B, Np, D, lead)
+
+
+def _head(ppnet, x, idx):
+    """final norm on the reserved rows + add-on 1x1 conv + sigmoid (deit:238; protopformer.py:162-172)."""
+    feats = ppnet.features
+    B, N, D = x.shape
+    k = idx.shape[1]
+    rows = ops.reserved_rows_map(idx, N)
+    nf = ops.layernorm_fwd_f32(x.reshape(B * N, D), feats.norm.weight, feats.norm.bias, LN_EPS, row_map=rows)
+    conv = ppnet.add_on_layers[0]
+    f = ops.linear_f32(nf, conv.weight, conv.bias, kind=2)
+    return f.reshape(B, 1 + k, conv.out_channels)
+
+
+def deit_tokens(ppnet, img, dp):
+    feats = ppnet.features
+    (layer, k), = ppnet.reserve_layer_nums
+    x = _embed(feats, img, 1)
+    B, N, D = x.shape
+    H = feats.num_heads
+    NP = (N + 3) // 4 * 4
+    hm = torch.empty((max(layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
+    x = x.reshape(B * N, D)
+    policy = cls_attn = idx = None
+    for i, blk in enumerate(feats.blocks):
+        if i == layer:
+            cls_attn, idx, policy = ops.rollout(hm, layer, B, N, k, lead=1)
+        n1 = ops.layernorm_fwd_f32(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        qkv = ops.linear_f32(n1, blk.attn.qkv.weight, blk.attn.qkv.bias)
+        ao = ops.attn_fwd_f32(qkv, B, H, N, D, policy=policy, self_keep=True, headmean=hm[i] if i < layer else None)
+        x1 = ops.linear_f32(ao, blk.attn.proj.weight, blk.attn.proj.bias, kind=3, res=x, rowscale=_dp(dp, 2 * i), rows_per_group=N)
+        x = _mlp(blk, x1, N, _dp(dp, 2 * i + 1))
+    return _head(ppnet, x.reshape(B, N, D), idx), cls_attn, idx
+
+
+def cait_tokens(ppnet, img, dp):
+    feats = ppnet.features
+    (layer, k), = ppnet.reserve_layer_nums
+    x = _embed(feats, img, 0)
+    B, N, D = x.shape
+    H = feats.num_heads
+    NP = (N + 3) // 4 * 4
+    depth = len(feats.blocks)
+    hm = torch.empty((depth, B, N, NP), dtype=torch.float32, device=x.device)
+    x = x.reshape(B * N, D)
+    for i, blk in enumerate(feats.blocks):
+        a = blk.attn
+        n1 = ops.layernorm_fwd_f32(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        qkv = ops.linear_f32(n1, a.qkv.weight, a.qkv.bias)
+        ao = ops.th_attn_fwd_f32(qkv, a.proj_l.weight, a.proj_l.bias, a.proj_w.weight, a.proj_w.bias, B, H, N, D, hm[i])
+        x1 = ops.linear_f32(ao, a.proj.weight, a.proj.bias, kind=3, res=x, rowscale=_dp(dp, 2 * i), rows_per_group=N, colscale=blk.gamma_1)
+        x = _mlp(blk, x1, N, _dp(dp, 2 * i + 1), colscale=blk.gamma_2)
+    N1 = N + 1
+    cls = feats.cls_token.detach().reshape(1, D).expand(B, D).contiguous()
+    xt = x.reshape(B, N, D)
+    policy = cls_attn = idx = None
+    rowmeans = []
+    for j, blk in enumerate(feats.blocks_token_only):
+        a = blk.attn
+        if j == layer:
+            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, k, lead=0, init_rows=torch.stack(rowmeans).contiguous())
+        u = torch.cat([cls.reshape(B, 1, D), xt], dim=1).reshape(B * N1, D)
+        n = ops.layernorm_fwd_f32(u, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        kk = ops.linear_f32(n, a.k.weight, a.k.bias)
+        vv = ops.linear_f32(n, a.v.weight, a.v.bias)
+        qq = ops.linear_f32(n.reshape(B, N1 * D)[:, :D], a.q.weight, a.q.bias)           # cls rows only (cait:73)
+        out, rowmean = ops.class_attn_fwd_f32(qq, kk, vv, policy, B, H, N1, D)
+        rowmeans.append(rowmean)
+        cls1 = ops.linear_f32(out, a.proj.weight, a.proj.bias, kind=3, res=cls, colscale=blk.gamma_1)
+        cls = _mlp(blk, cls1, 1, None, colscale=blk.gamma_2)
+    u_out = torch.cat([cls.reshape(B, 1, D), xt], dim=1).contiguous()
+    return _head(ppnet, u_out, idx), cls_attn, idx
+
+
+def tokens(ppnet, img, dp):
+    from .deit import MyVisionTransformer
+    if torch.is_grad_enabled() and any(p.requires_grad for p in ppnet.parameters()):
+        raise RuntimeError("the fp32 verification mode (PPNet.precise / PPF_PRECISE=1) is forward-only: call it under torch.no_grad()")
+    fn = deit_tokens if isinstance(ppnet.features, MyVisionTransformer) else cait_tokens
+    return fn(ppnet, img, dp)

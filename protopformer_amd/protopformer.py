@@ -20,7 +20,9 @@ from .flat import FlatStore
 ARCHS = {
     "deit_tiny_patch16_224": dict(kind="deit", embed_dim=192, depth=12, num_heads=3),
     "deit_small_patch16_224": dict(kind="deit", embed_dim=384, depth=12, num_heads=6),
+    "deit_base_patch16_224": dict(kind="deit", embed_dim=768, depth=12, num_heads=12),           # deit:315-328
     "cait_xxs24_224": dict(kind="cait", embed_dim=192, depth=24, num_heads=4, init_scale=1e-5),
+    "cait_s24_224": dict(kind="cait", embed_dim=384, depth=24, num_heads=8, init_scale=1e-5),    # cait:379-383, cait_features.py:16
 }
 
 
@@ -80,7 +82,7 @@ class ProtoLayerFn(torch.autograd.Function):
         store = ppnet.flat_store()
         store.attach_all_grads()
         B, T1, Dp = f.shape
-        df = torch.zeros_like(f)
+        df = ops.zeros(f.shape, f.dtype, f.device)
         lane = wgrad_lane(store)      # prototype gradients feed only the optimizer: side stream, under the backbone backward
         torch.autograd.Variable._execution_engine.queue_callback(lane.join)     # ... joined when this backward pass ends
         if g_l is not None or g_full is not None:
@@ -158,7 +160,7 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, up):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * up, None          # chain rule with the upstream scalar (autograd bookkeeping)
+        return ops.scale_by_scalar(dlogits, up.float().contiguous()), None          # chain rule with the upstream (device) scalar
 
 
 class CrossEntropyLoss(nn.Module):
@@ -224,6 +226,7 @@ class PPNet(nn.Module):
         self.scale = self.prototype_shape[1] ** -0.5
         self._flat = None
         self._ppc_cache = None
+        self.precise = False            # True (or PPF_PRECISE=1): fp32 verification forward (protopformer_amd/precise.py), no_grad only
         from .backbone import DEIT_FNS
         if isinstance(features, MyVisionTransformer):
             self._arch_fns = DEIT_FNS
@@ -249,9 +252,13 @@ class PPNet(nn.Module):
     def _hook_params(self):
         return [p for p in list(self.features.parameters()) + list(self.add_on_layers.parameters()) if p.requires_grad]
 
-    def _apply(self, fn, *a, **k):                    # .to()/.cuda()/.float(): the flat views are re-created lazily
-        self._flat = None
-        return super()._apply(fn, *a, **k)
+    def _apply(self, fn, *a, **k):
+        """.to()/.cuda()/.float(): if the parameters were really re-materialised the flat views are re-created lazily (an optimizer
+        built on the old store then refuses to step, FlatAdamW._check_store); a no-op move keeps the store."""
+        out = super()._apply(fn, *a, **k)
+        if self._flat is not None and not self._flat.still_flat():
+            self._flat = None
+        return out
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -270,6 +277,10 @@ class PPNet(nn.Module):
         B = x.shape[0]
         rates = self.features.droppath_rates()
         dp = droppath_scales(rates, B, x.device, self.training)
+        if self.precise or os.environ.get("PPF_PRECISE", "0") != "0":
+            from . import precise
+            self.flat_store()
+            return precise.tokens(self, x, dp)
         return TokensFn.apply(x, self, dp, *self._hook_params())
 
     def _branches(self, x, want_dist):
@@ -291,7 +302,7 @@ class PPNet(nn.Module):
         f, cls_attn, idx, act_full, dist, logits, lg, ll = self._branches(x, want_dist=False)
         self._ppc_cache = (cls_attn, idx)
         total_proto_act = act_full.reshape(B, self.num_prototypes, s, s)
-        attn_loss = torch.zeros(1, device=logits.device)
+        attn_loss = ops.zeros((1,), torch.float32, logits.device)
         return logits, (None, attn_loss, total_proto_act, cls_attn, self.num_patches)
 
     def push_forward(self, x):

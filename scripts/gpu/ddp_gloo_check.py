@@ -15,8 +15,8 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
 
-def build():
-    torch.manual_seed(7)
+def build(seed=7):
+    torch.manual_seed(seed)
     m = construct_PPNet("deit_tiny_patch16_224", pretrained=False, img_size=224, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[11],
                         reserve_token_nums=[81], use_global=True, use_ppc_loss=True, global_proto_per_class=5, add_on_layers_type="regular").to(dev)
     m.train()
@@ -27,7 +27,13 @@ def build():
 g = torch.Generator(device=dev).manual_seed(100)
 img_all = torch.randn(2 * 8, 3, 224, 224, device=dev, generator=g); lab_all = torch.randint(0, 20, (16,), device=dev, generator=g)
 img, lab = img_all[rank * 8:(rank + 1) * 8], lab_all[rank * 8:(rank + 1) * 8]
-m = build(); opt = FlatAdamW(m, weight_decay=0.05, ema_decay=0.999); sync = make_grad_sync(m); crit = CrossEntropyLoss()
+# different seeds per rank, as the reference (main.py:254 seed + rank): make_grad_sync() must make the replicas identical
+m = build(7 + rank); opt = FlatAdamW(m, weight_decay=0.05, ema_decay=0.999); sync = make_grad_sync(m, opt); crit = CrossEntropyLoss()
+p0 = m.flat_store().params
+lo, hi = p0.clone(), p0.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert bool(torch.equal(lo, hi)), "rank-0 broadcast did not make the replicas identical"
+assert bool(torch.equal(opt.ema, p0)), "EMA copy must follow the broadcast parameters"
 for it in range(3):
     loss, cov, mean = train_one_step(m, crit, img, lab, opt, epoch=20, grad_sync=sync)
 torch.cuda.synchronize()

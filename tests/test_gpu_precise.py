@@ -1,0 +1,98 @@
+"""The fp32 verification mode (PPNet.precise, protopformer_amd/precise.py + csrc/precise.hip) against the REFERENCE-generated
+fixtures at the north-star tolerance: 1e-3 relative on logits / losses / activations, bit-exact reserved-token indices.
+
+The product path computes its GEMMs / attention with bf16 operands (gated at bf16-level tolerances in test_gpu_e2e.py /
+test_gpu_baseline_configs.py); this mode runs the same orchestration, rollout, reservation, prototype, PPC and CE kernels with
+fp32 operands everywhere, so any disagreement beyond 1e-3 is a kernel or orchestration bug, not rounding."""
+import pytest
+import torch
+
+from helpers import assert_close, build_micro, micro, rel_err
+from oracle import ppf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 rel fp32"
+
+
+@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz"])
+def test_precise_forward_and_loss_match_reference_fixture(name):
+    from protopformer_amd.protopformer import CrossEntropyLoss
+    sd, cfg, z = micro(name)
+    m = build_micro(cfg, sd)
+    m.precise = True
+    img, label = torch.from_numpy(z["img"]).cuda(), torch.from_numpy(z["label"]).cuda()
+    with torch.no_grad():
+        m.eval()
+        logits, (cls_attn, dist, lg, ll) = m(img)
+        assert_close(cls_attn, z["eval/cls_token_attn"], rtol=TOL, atol=1e-7, what="cls_token_attn")
+        ref_idx = torch.from_numpy(z["eval/cls_token_attn"]).topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
+        assert torch.equal(m._tokens(img)[2].cpu().long(), ref_idx), "reserved-token indices must be bit-exact"
+        assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+        assert rel_err(lg, z["eval/logits_global"]) < TOL and rel_err(ll, z["eval/logits_local"]) < TOL
+        # distances: d = x2 - 2xp + p2 cancels, so compare on the scale of its terms (SURVEY 8(c) tolerances)
+        d_ref = torch.from_numpy(z["eval/distances"])
+        assert_close(dist, d_ref, rtol=TOL, atol=1e-5 * cfg["proto_dim"], what="eval distances")
+        _, acts = m.push_forward(img)
+        a_ref = torch.from_numpy(z["eval/push_proto_acts"])
+        far = d_ref.reshape(a_ref.shape) >= 0.05                        # log-similarity is steep near d = 0
+        assert_close(acts.cpu()[far], a_ref[far], rtol=TOL, atol=1e-5, what="push_forward activations (d >= 0.05)")
+        m.train()
+        logits, aux = m(img)
+        assert aux[0] is None and aux[4] == 16
+        assert rel_err(logits, z["train/logits"]) < TOL
+        assert_close(aux[3], z["train/cls_attn_rollout"], rtol=TOL, atol=1e-7, what="cls_attn_rollout")
+        ce = CrossEntropyLoss()(logits, label)
+        cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label)
+        loss = ce + 0.1 * cov + 0.5 * mean
+        for nm, val in (("ce", ce), ("ppc_cov", cov), ("ppc_mean", mean), ("loss", loss)):
+            assert rel_err(val, z[f"train/{nm}"]) < TOL, (nm, float(val), float(z[f"train/{nm}"]))
+
+
+def test_precise_mode_is_forward_only():
+    sd, cfg, z = micro("micro_deit.npz")
+    m = build_micro(cfg, sd)
+    m.precise = True
+    m.train()
+    with pytest.raises(RuntimeError, match="forward-only"):
+        m(torch.from_numpy(z["img"]).cuda())
+
+
+@pytest.mark.parametrize("arch,k,layer,C,gpc,P,Dp", [("deit_small_patch16_224", 81, 11, 200, 10, 2000, 384),
+                                                      ("cait_xxs24_224", 121, 1, 196, 5, 1960, 192)])
+def test_precise_baseline_heads_vs_oracle(arch, k, layer, C, gpc, P, Dp):
+    """BASELINE configs 3 and 5 with their real heads (2000x384 / 1960x192 prototypes) at B=2: the fp32 mode must reproduce the
+    CPU oracle's reservation exactly and its logits / CE / PPC terms within 1e-3."""
+    from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
+    cfg = O.make_cfg(arch, P, Dp, C, layer, k, global_per_class=gpc)
+    sd = O.init_state_dict(cfg, seed=11)
+    g = torch.Generator().manual_seed(12)
+    for k_ in sd:
+        if k_.endswith(".bias") and "add_on" not in k_:
+            sd[k_] = 0.05 * torch.randn(sd[k_].shape, generator=g)
+        if "qkv.weight" in k_:
+            sd[k_] = sd[k_] * 6.0                                       # peaky attention => a well-separated top-k
+        if "gamma_" in k_:
+            sd[k_] = 0.1 + 0.05 * torch.rand(sd[k_].shape, generator=g)  # LayerScale large enough to matter
+    m = construct_PPNet(arch, pretrained=False, prototype_shape=(P, Dp, 1, 1), num_classes=C, reserve_layers=[layer], reserve_token_nums=[k],
+                        use_global=True, use_ppc_loss=True, global_proto_per_class=gpc, add_on_layers_type="regular")
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    m.precise = True
+    for blk in m.features.blocks:
+        blk.drop_path_rate = 0.0
+    img = torch.randn(2, 3, 224, 224, generator=g); label = torch.tensor([3, C - 1])
+    with torch.no_grad():
+        logits, aux = m(img.cuda())
+        ce = CrossEntropyLoss()(logits, label.cuda())
+        cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label.cuda())
+        out = O.ppnet_forward(sd, img, cfg, train=True)
+        _, parts = O.train_loss(out, label, cfg, with_ppc=True)
+    assert_close(aux[3], out["cls_token_attn"], rtol=TOL, atol=1e-7, what="cls rollout")
+    srt = out["cls_token_attn"].sort(dim=-1, descending=True)[0]
+    if float((srt[:, k - 1] - srt[:, k]).min()) > 1e-5 * float(srt.max()):          # tie-free at the boundary: indices must be exact
+        assert torch.equal(m._ppc_cache[1].cpu().long(), out["reserve_idx"])
+    assert rel_err(logits, out["logits"]) < TOL, rel_err(logits, out["logits"])
+    assert rel_err(ce, parts["ce"]) < TOL and rel_err(cov, parts["ppc_cov"]) < TOL and rel_err(mean, parts["ppc_mean"]) < TOL
+    far = out["distances"] >= 0.05
+    assert_close(aux[2].cpu()[far], out["total_proto_act"][far], rtol=TOL, atol=1e-5, what="total_proto_act (d >= 0.05)")
