@@ -287,7 +287,8 @@ def main():
         try:
             for _ in range(2):
                 step(); done += 1
-            _lib.call("ppf_gemm_probe", 1)
+            if os.environ.get("PPF_BENCH_GRAPH_PROBE", "1") != "0":
+                _lib.call("ppf_gemm_probe", 1)
             step(); done += 1                                         # capture + first replay
             _lib.call("ppf_gemm_probe", 0)
             torch.cuda.synchronize()

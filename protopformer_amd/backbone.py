@@ -148,6 +148,7 @@ class WgradLane:
         self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
         self.stream = torch.cuda.Stream(device=device) if self.enabled else None
         self.last_read = {}
+        self.held = []              # while a step is being captured: tensors the lane reads, kept alive until the next join()
 
     def submit(self, fn, reads, tag=None):
         if not self.enabled or (tag is not None and os.environ.get("PPF_LANE_" + tag, "1") == "0"):
@@ -158,8 +159,12 @@ class WgradLane:
             fn()
         done = torch.cuda.Event()
         done.record(self.stream)
+        capturing = torch.cuda.is_current_stream_capturing()
         for t in reads:
-            t.record_stream(self.stream)
+            if capturing:
+                self.held.append(t)           # record_stream is not capture-safe: keep the block allocated until the lane is joined
+            else:
+                t.record_stream(self.stream)
             self.last_read[t.data_ptr()] = done
 
     def before_overwrite(self, t):
@@ -171,6 +176,7 @@ class WgradLane:
         if self.enabled:
             torch.cuda.current_stream().wait_stream(self.stream)
         self.last_read.clear()
+        self.held.clear()
 
 
 def wgrad_lane(store):

@@ -329,12 +329,12 @@ def make_grad_sync(ppnet, optimizer=None, n_chunks=4):
     st = ppnet.flat_store()
     block_offsets = []
     for name, p, o, n in st.entries:
-        if name.startswith("blocks.") and name.split(".")[2] == "norm1" and name.endswith("weight"):
+        if name.startswith("features.blocks.") and name.split(".")[3] == "norm1" and name.endswith("weight"):
             block_offsets.append(o)
     depth = len(block_offsets)
     per = max(1, math.ceil(depth / max(1, n_chunks - 1)))
     cuts = sorted({block_offsets[i] for i in range(0, depth, per)})
-    norm_off = next(o for name, p, o, n in st.entries if name == "norm.weight")
+    norm_off = next(o for name, p, o, n in st.entries if name == "features.norm.weight")
     bounds = [0] + [c for c in cuts if c > 0] + [norm_off, st.total]
     bounds = sorted(set(bounds))
     sync = GradSync(st.grads, bounds)

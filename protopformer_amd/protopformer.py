@@ -242,7 +242,9 @@ class PPNet(nn.Module):
             dev = self.prototype_vectors.device
             if dev.type != "cuda":
                 raise RuntimeError("protopformer_amd runs on an MI355X only: move the model to cuda (no CPU fallback path)")
-            groups = [("features", list(self.features.named_parameters())), ("add_on_layers", list(self.add_on_layers.named_parameters())),
+            # entry names are the model's state-dict keys
+            groups = [("features", [("features." + n, p) for n, p in self.features.named_parameters()]),
+                      ("add_on_layers", [("add_on_layers." + n, p) for n, p in self.add_on_layers.named_parameters()]),
                       ("prototype_vectors", [("prototype_vectors", self.prototype_vectors)]),
                       ("prototype_vectors_global", [("prototype_vectors_global", self.prototype_vectors_global)])]
             self._flat = FlatStore(self, groups)

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import golden_inputs as gi
-from helpers import assert_close, load_npz, micro, rel_err
+from helpers import assert_close, load_npz, micro, rel_err, report
 from oracle import ppf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -141,16 +141,19 @@ def test_micro_cait_against_reference_fixture():
     img, label = torch.from_numpy(z["img"]).cuda(), torch.from_numpy(z["label"]).cuda()
     m.eval()
     logits, (cls_attn, dist, lg, ll) = m(img)
-    assert rel_err(cls_attn, z["eval/cls_token_attn"]) < 5e-2, rel_err(cls_attn, z["eval/cls_token_attn"])
+    assert rel_err(cls_attn, z["eval/cls_token_attn"]) < 6e-2, rel_err(cls_attn, z["eval/cls_token_attn"])     # measured 2.6e-2
     ref_idx = torch.from_numpy(z["eval/cls_token_attn"]).topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
     assert torch.equal(m._tokens(img)[2].cpu().long(), ref_idx), "reserved tokens differ from the reference"
-    TOL = 6e-2
+    TOL = 2.5e-3              # measured: logits 2.6e-4, distances 8.2e-4 (gates <= 3x)
+    report("micro_cait_eval", logits=rel_err(logits, z["eval/logits"]), cls_attn=rel_err(cls_attn, z["eval/cls_token_attn"]), dist=rel_err(dist, z["eval/distances"]))
     assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+    assert rel_err(dist, z["eval/distances"]) < TOL, rel_err(dist, z["eval/distances"])
     m.train()
     logits, aux = m(img)
     ce = CrossEntropyLoss()(logits, label)
     cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label)
     loss = ce + 0.1 * cov + 0.5 * mean
+    report("micro_cait_train", **{name: rel_err(val, z[f"train/{name}"]) for name, val in (("ce", ce), ("ppc_cov", cov), ("ppc_mean", mean), ("loss", loss))})
     for name, val in (("ce", ce), ("ppc_cov", cov), ("ppc_mean", mean), ("loss", loss)):
         assert rel_err(val, z[f"train/{name}"]) < TOL, (name, float(val), float(z[f"train/{name}"]))
     loss.backward()
@@ -167,6 +170,7 @@ def test_micro_cait_against_reference_fixture():
         if float(ref.abs().max()) < 1e-7 or name.endswith("proj_l.bias") or name.endswith("attn.k.bias"):   # zero true gradient
             continue
         cos[name] = float(torch.dot(gflat, ref) / (gflat.norm() * ref.norm()).clamp_min(1e-30))
+    report("micro_cait_grads", worst_cos=min(cos.values()))
     bad = {k: v for k, v in cos.items() if v < 0.93}
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
@@ -231,8 +235,10 @@ def test_real_shape_cait_xxs24_train_step_vs_oracle():
         out = O.ppnet_forward(sd, img, cfg, train=True, force_idx=my_idx)
         _, parts = O.train_loss(out, label, cfg, with_ppc=True)
     # bf16 operands through 26 blocks: tolerances as in the DeiT real-shape test
-    assert rel_err(logits, out["logits"]) < 5e-2
-    assert rel_err(ce, parts["ce"]) < 3e-2 and rel_err(cov, parts["ppc_cov"]) < 8e-2 and rel_err(mean, parts["ppc_mean"]) < 8e-2
+    report("real_shape_cait_peaky", logits=rel_err(logits, out["logits"]), ce=rel_err(ce, parts["ce"]), cov=rel_err(cov, parts["ppc_cov"]), mean=rel_err(mean, parts["ppc_mean"]))
+    # measured: logits 1.2e-4, CE 3.4e-5, PPC 1.8e-5 / 4.8e-5
+    assert rel_err(logits, out["logits"]) < 4e-4
+    assert rel_err(ce, parts["ce"]) < 1e-4 and rel_err(cov, parts["ppc_cov"]) < 6e-5 and rel_err(mean, parts["ppc_mean"]) < 1.5e-4
     m.flat_store().zero_grad()
     f, _, idx = m._tokens(img.cuda())
     w = torch.randn(f.shape, generator=g)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, micro, rel_err
+from helpers import assert_close, micro, rel_err, report
 from oracle import ppf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -36,17 +36,24 @@ def test_micro_deit_eval_train_against_reference_fixture():
     m.eval()
     logits, (cls_attn, dist, lg, ll) = m(img)
     assert dist.shape == z["eval/distances"].shape
-    assert_close(cls_attn, z["eval/cls_token_attn"], rtol=3e-2, atol=1e-4, what="cls_token_attn (bf16 backbone)")
+    assert rel_err(cls_attn, z["eval/cls_token_attn"]) < 3e-3, rel_err(cls_attn, z["eval/cls_token_attn"])     # measured 8.1e-4 of its maximum
     ref_idx = torch.from_numpy(z["eval/cls_token_attn"]).topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
     my_idx = cls_attn.cpu().topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
     assert torch.equal(my_idx, ref_idx), "reserved tokens differ from the reference on the micro fixture"
-    # bf16 operand rounding through 3 blocks feeding the steep log-similarity of a tiny head (P=20, Dp=32, 9 tokens: nothing
-    # averages out): measured 3.3e-2 on the logits here, 1.5e-3 at real shapes (next test)
-    TOL = 6e-2
+    # bf16 MFMA operands through the blocks, fp32 everywhere else.  Measured on MI355X (gpurun_out/tol_report.jsonl, round 2):
+    # logits 3.3e-4, global / local logits 6.7e-4 / 5.3e-4, distances 9.7e-4 (of the largest), push activations 1.2e-3;
+    # gates at <= 3x the measurement (the north star's 1e-3 is met on the logits; the fp32 mode of test_gpu_precise.py holds
+    # every quantity to 1e-3)
+    TOL = 2e-3
+    report("micro_deit_eval", logits=rel_err(logits, z["eval/logits"]), lg=rel_err(lg, z["eval/logits_global"]), ll=rel_err(ll, z["eval/logits_local"]),
+           cls_attn=rel_err(cls_attn, z["eval/cls_token_attn"]), dist=rel_err(dist, z["eval/distances"]))
     assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+    # eval `distances` VALUES (not only the shape): bf16 tokens against fp32 prototypes, error relative to the largest distance
+    assert rel_err(dist, z["eval/distances"]) < TOL, rel_err(dist, z["eval/distances"])
     assert rel_err(lg, z["eval/logits_global"]) < TOL and rel_err(ll, z["eval/logits_local"]) < TOL
     cls2, acts = m.push_forward(img)
-    assert rel_err(acts, z["eval/push_proto_acts"]) < 0.15
+    report("micro_deit_push", acts=rel_err(acts, z["eval/push_proto_acts"]))
+    assert rel_err(acts, z["eval/push_proto_acts"]) < 4e-3
 
     m.train()
     crit = CrossEntropyLoss()
@@ -55,13 +62,14 @@ def test_micro_deit_eval_train_against_reference_fixture():
     ce = crit(logits, label)
     cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label)
     loss = ce + 0.1 * cov + 0.5 * mean
+    report("micro_deit_train", **{name: rel_err(val, z[f"train/{name}"]) for name, val in (("ce", ce), ("ppc_cov", cov), ("ppc_mean", mean), ("loss", loss))})
+    gates = {"ce": 6e-5, "ppc_cov": 4e-4, "ppc_mean": 2e-4, "loss": 1e-5}           # measured 1.8e-5 / 1.1e-4 / 6.6e-5 / 1.8e-6
     for name, val in (("ce", ce), ("ppc_cov", cov), ("ppc_mean", mean), ("loss", loss)):
-        assert rel_err(val, z[f"train/{name}"]) < TOL, (name, float(val), float(z[f"train/{name}"]))
+        assert rel_err(val, z[f"train/{name}"]) < gates[name], (name, float(val), float(z[f"train/{name}"]))
     loss.backward()
-    # Gradients vs the reference fixture.  Two effects bound the agreement (measured with scripts/diag_e2e.py):
-    #  * bf16 operands in every backward GEMM: per-tensor cosine >= 0.997 on a max-pool-free loss (next test);
-    #  * max-pool arg-max routing is discontinuous: a bf16-level change of a near-tied activation moves a prototype's
-    #    whole gradient to another token, which shows up in every upstream tensor (cosine ~0.97-0.99).
+    # Gradients vs the reference fixture: every tensor's cosine with the reference gradient, measured worst 0.99996 here.
+    # (With peaky attention -- next test -- the max-pool's arg-max routing can flip on a near-tie and move a prototype's whole
+    #  gradient to another token: cosine 0.94 for the affected tensors there.)
     cos = {}
     for name, p in m.named_parameters():
         if not p.requires_grad:
@@ -75,7 +83,8 @@ def test_micro_deit_eval_train_against_reference_fixture():
         if float(ref.abs().max()) < 1e-7:
             continue
         cos[name] = float(torch.dot(g, ref) / (g.norm() * ref.norm()))
-    bad = {k: v for k, v in cos.items() if v < 0.93}
+    report("micro_deit_grads", worst_cos=min(cos.values()))
+    bad = {k: v for k, v in cos.items() if v < 0.9998}
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
 
@@ -132,9 +141,12 @@ def test_real_shape_train_step_vs_oracle():
     out = O.ppnet_forward(params, img, cfg, train=True, force_idx=my_idx)
     loss_ref, parts = O.train_loss(out, label, cfg, with_ppc=True)
     loss_ref.backward()
-    assert rel_err(logits, out["logits"]) < 3e-2
-    assert rel_err(ce, parts["ce"]) < 3e-2 and rel_err(cov, parts["ppc_cov"]) < 5e-2 and rel_err(mean, parts["ppc_mean"]) < 5e-2
     rows = _grad_agreement(m, params)
+    report("real_shape_tiny_peaky", logits=rel_err(logits, out["logits"]), ce=rel_err(ce, parts["ce"]), cov=rel_err(cov, parts["ppc_cov"]),
+           mean=rel_err(mean, parts["ppc_mean"]), worst_cos=min(c for _, c in rows.values()))
+    # measured (attention sharpened 6x on purpose, far peakier than any trained model): logits 1.5e-3, CE 2.4e-4, PPC 1.7e-5
+    assert rel_err(logits, out["logits"]) < 4.5e-3
+    assert rel_err(ce, parts["ce"]) < 8e-4 and rel_err(cov, parts["ppc_cov"]) < 6e-5 and rel_err(mean, parts["ppc_mean"]) < 6e-5
     assert min(c for _, c in rows.values()) > 0.93, {k: v for k, v in rows.items() if v[1] <= 0.93}     # arg-max routing flips, see above
 
     # backbone backward in isolation: L = sum(w * f) on the add-on tokens (no max-pool routing) -> every parameter gradient
@@ -146,14 +158,16 @@ def test_real_shape_train_step_vs_oracle():
     params = {k: v.clone().requires_grad_(k not in O.FROZEN_KEYS) for k, v in sd.items()}
     out = O.ppnet_forward(params, img, cfg, train=True, force_idx=idx.cpu().long())
     fo = torch.cat([out["cls_tokens"], out["tokens"]], dim=1)
-    assert rel_err(f, fo) < 8e-2
     (fo * w).sum().backward()
     rows = _grad_agreement(m, params)
+    report("real_shape_tiny_peaky_backbone", f=rel_err(f, fo), worst_cos=min(c for _, c in rows.values()), median_rel=sorted(r for r, _ in rows.values())[len(rows) // 2],
+           worst_rel=max(r for r, _ in rows.values()))
+    assert rel_err(f, fo) < 8e-2                              # measured 4.4e-2 (sigmoid outputs after 12 peaky bf16 layers)
     assert len(rows) > 140
     rels = sorted(r for r, _ in rows.values())
     worst_cos = min(c for _, c in rows.values())
     # measured: cosine >= 0.997 for every tensor, rel-to-max error median 3e-2, worst 0.2 (bf16 drift over 12 peaky layers)
-    assert worst_cos > 0.99 and rels[len(rels) // 2] < 6e-2 and rels[-1] < 0.3, (rels[len(rels) // 2], rels[-1], worst_cos)
+    assert worst_cos > 0.992 and rels[len(rels) // 2] < 6e-2 and rels[-1] < 0.4, (rels[len(rels) // 2], rels[-1], worst_cos)
 
 
 def test_two_rank_data_parallel_on_one_gpu():
@@ -196,7 +210,10 @@ def test_reserved_token_compaction_matches_masked_blocks(monkeypatch):
         res[mode] = dict(f=f.detach().clone(), idx=idx.clone(), logits=logits.detach().clone(), loss=float(ce.detach()),
                          grads=m.flat_store().grads.clone())
     a, b = res["1"], res["0"]
+    report("compact_vs_masked_tiny", f=rel_err(a["f"], b["f"]), logits=rel_err(a["logits"], b["logits"]), loss=abs(a["loss"] - b["loss"]) / abs(b["loss"]),
+           cos=float(torch.dot(a["grads"], b["grads"]) / (a["grads"].norm() * b["grads"].norm())))
     assert torch.equal(a["idx"], b["idx"])                      # the reservation itself happens before the compaction
-    assert rel_err(a["f"], b["f"]) < 2e-2 and rel_err(a["logits"], b["logits"]) < 2e-2 and abs(a["loss"] - b["loss"]) < 2e-3 * abs(b["loss"])
+    # measured: tokens 2.7e-3, logits 1.3e-4, loss 3.8e-6, gradient cosine 0.99995
+    assert rel_err(a["f"], b["f"]) < 8e-3 and rel_err(a["logits"], b["logits"]) < 4e-4 and abs(a["loss"] - b["loss"]) < 2e-5 * abs(b["loss"])
     cos = float(torch.dot(a["grads"], b["grads"]) / (a["grads"].norm() * b["grads"].norm()))
-    assert cos > 0.995, cos
+    assert cos > 0.9998, cos
