@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of the full ProtoPFormer train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config deit_small|deit_tiny|cait_xxs24] [--no-graph]
+    python bench.py --gpus N --steps K --warmup W [--config deit_small|deit_tiny|cait_xxs24] [--graph]
 
 With --gpus N > 1 and no torch.distributed environment, this process only LAUNCHES: it spawns N rank processes (one per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) before anything here touches the GPU, relays rank 0's
@@ -10,8 +10,10 @@ JSON line and exits non-zero if any rank failed.  Started by `python -m torch.di
 A "step" (tools/engine_proto.py:41-81): resident synthetic batch -> forward (train branch, DropPath 0.1 active) -> CE +
 0.1*PPC_sigma + 0.5*PPC_mu -> backward -> gradient all-reduce (N > 1) -> AdamW (reference param groups) -> EMA.
 Default workload = BASELINE.json configs[2]: deit_small_patch16_224, 2000x384 prototypes, 200 classes, k = 81, batch 256 per GPU
-(weak scaling), bf16 MFMA operands / fp32 accumulate, random-init weights, synthetic N(0,1) images.  The step is captured once
-into a HIP graph (engine.GraphedTrainStep) and replayed; --no-graph enqueues every kernel from the host each step.
+(weak scaling), bf16 MFMA operands / fp32 accumulate, random-init weights, synthetic N(0,1) images.  Kernels are enqueued from
+the host on two HIP streams each step; --graph replays one captured HIP graph per step instead (engine.GraphedTrainStep: measured
+SLOWER on ROCm 7.2 -- hipGraphLaunch re-enqueues every node, 12.5 ms of host time per replay, and spreads the two-stream step over
+four queues with half the overlap: 23.6-27.0 ms vs 18.9 ms per step, profiles/r2_graph_timeline.txt -- so it is opt-in).
 Prints ONE JSON line (rank 0) with the roofline of the dominant kernel (HIP events on its launch stream, recorded inside the
 timed region) and the CPU baseline (oracle port on the host cores, bounded sample).
 """
@@ -233,7 +235,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="deit_small")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel from the host each step instead of replaying a captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of enqueueing every kernel from the host")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the multi-rank launch + all-reduce plumbing (no GPU, no measurement)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
     args = ap.parse_args()
@@ -271,8 +273,8 @@ def main():
     label = torch.randint(0, cfg["C"], (batch,), device=device, generator=g)
 
     graphed = None
-    graph_note = "eager (--no-graph)"
-    if not args.no_graph:
+    graph_note = "kernels enqueued from the host each step, two HIP streams"
+    if args.graph:
         graphed = GraphedTrainStep(model, crit, opt, epoch=20, grad_sync=sync, warmup=2, adopt_inputs=True)     # the batch is resident
 
     def step():
@@ -280,26 +282,22 @@ def main():
             return graphed(img, label)
         return train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
 
-    # warm-up: two eager steps, then (graph mode) the capture with the roofline probe ON -- its HIP events become event-record
-    # nodes that every replay re-records on the weight-gradient stream -- then the remaining warm-up replays
     done = 0
     if graphed is not None:
         try:
-            for _ in range(2):
+            for _ in range(3):                                        # two eager steps, then capture + first replay
                 step(); done += 1
-            if os.environ.get("PPF_BENCH_GRAPH_PROBE", "1") != "0":
-                _lib.call("ppf_gemm_probe", 1)
-            step(); done += 1                                         # capture + first replay
-            _lib.call("ppf_gemm_probe", 0)
             torch.cuda.synchronize()
             graph_note = "one captured HIP graph per step (engine.GraphedTrainStep), replayed"
         except Exception as e:                                        # capture refused (e.g. a collective that cannot be captured)
-            _lib.call("ppf_gemm_probe", 0)
-            graph_note = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:200]})"
+            graph_note = f"host-enqueued (graph capture failed: {type(e).__name__}: {str(e)[:200]})"
             graphed = None
             torch.cuda.synchronize()
     for _ in range(max(0, args.warmup - done)):
         step()
+    # roofline probe: HIP events around every launch of the dominant kernel (wgrad GEMM) on its launch stream.  Event-record nodes of
+    # a captured graph cannot be read back on ROCm 7.2 (hipEventElapsedTime: invalid resource handle), so in --graph mode the probe
+    # runs over 3 host-enqueued steps AFTER the timed region.
     if graphed is None:
         _lib.call("ppf_gemm_probe", 1)
     if world > 1:
@@ -313,16 +311,22 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    probe_note = "HIP events around every launch inside the timed region"
     if graphed is None:
         _lib.call("ppf_gemm_probe", 0)
+    else:
+        _lib.call("ppf_gemm_probe", 1)
+        for _ in range(3):
+            train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
+        torch.cuda.synchronize()
+        _lib.call("ppf_gemm_probe", 0)
+        probe_note = "HIP events around every launch of 3 host-enqueued steps after the timed region (graph nodes cannot be timed)"
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     import ctypes
     c_ms, c_n, c_fl, c_by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-    probe_note = "HIP events around every launch inside the timed region" if graphed is None else \
-        "HIP event-record nodes of the captured step: durations of the launches of the LAST timed replay"
     try:
         _lib.call("ppf_gemm_probe_read", ctypes.addressof(c_ms), ctypes.addressof(c_n), ctypes.addressof(c_fl), ctypes.addressof(c_by))
     except RuntimeError as e:

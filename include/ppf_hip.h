@@ -189,6 +189,11 @@ int ppf_reserved_rows_map(const int* idx, int* rows, int B, int k, int N, ppf_st
 int ppf_gather_rows(const void* src, const int* rows, void* dst, int nrows, int row_bytes, ppf_stream_t stream);
 int ppf_scatter_rows(const void* src, const int* rows, void* dst, int nrows_src, int nrows_dst, int row_bytes, ppf_stream_t stream);
 int ppf_memset_zero(void* ptr, size_t bytes, ppf_stream_t stream);
+/* input pipeline finisher (tools/datasets.py:280-336: ToTensor + Normalize; timm RandomErasing 'pixel'): uint8 [B][H][W][3] frames
+ * -> fp32 [B][3][H][W] = (x/255 - mean)/std; rects [B][4] = (y, x, h, w) erase rectangles filled with N(0,1) noise (h == 0: none;
+ * rects == NULL: no erasing); mean3 / std3 are HOST pointers; state_u64 (device, optional) = step counter mixed into the noise key. */
+int ppf_image_finish_u8(const void* in_u8_hwc, float* out_nchw, int B, int H, int W, const float* mean3, const float* std3,
+                        const int* rects, uint64_t seed, const void* state_u64, ppf_stream_t stream);
 /* out = x * (*scalar_dev): chain rule with a device-resident upstream scalar (autograd of nn.CrossEntropyLoss, main.py:390) */
 int ppf_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, ppf_stream_t stream);
 

@@ -58,6 +58,7 @@ SIGS = {
     "ppf_gather_rows": "ppp" "ii" "s",
     "ppf_scatter_rows": "ppp" "iii" "s",
     "ppf_memset_zero": "pz" "s",
+    "ppf_image_finish_u8": "pp" "iii" "ppp" "Lp" "s",
     "ppf_scale_by_scalar": "ppp" "l" "s",
 }
 

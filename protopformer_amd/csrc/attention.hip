@@ -16,6 +16,7 @@
 //   attn_bwd_dkv  dK, dV,                        one wave per 32-key tile
 #include "ppf_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -69,9 +70,35 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int o) {
 }
 __device__ __forceinline__ int reg_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// Stage `rows` rows (HD bf16 each) from src (row stride ld) into a swizzled LDS tile.  Rows beyond nvalid are
+// Stage ROWS rows (HD bf16 each) from src (row stride ld) into a swizzled LDS tile.  Rows beyond nvalid are
 // zero-filled, or (CLAMP) replicate the last valid row so that padded keys produce finite scores that never
 // exceed the true row maximum (they are then removed by keep = 0).
+// Two steps so that a kernel can put ALL its global loads in flight before the first LDS write: the one-loop form compiled to
+// load -> s_waitcnt vmcnt(0) -> ds_write per iteration, i.e. 7 dependent HBM round trips per workgroup before any MFMA
+// (SQ_WAIT_ANY 43-57 % of the wave cycles, profiles/r2_attn_pmc.txt).
+template <int HD, int ROWS, int NTHR>
+struct Stage {
+    static constexpr int CH = HD / 8, ITER = (ROWS * CH + NTHR - 1) / NTHR;
+    uint4 v[ITER];
+    template <bool CLAMP>
+    __device__ __forceinline__ void load(const bf16_t* src, int ld, int row_begin, int nvalid, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTHR, r = i / CH, c = i - r * CH;
+            int gr = row_begin + r;
+            if (CLAMP) gr = min(gr, nvalid - 1);
+            v[it] = make_uint4(0, 0, 0, 0);
+            if (i < ROWS * CH && gr < nvalid) v[it] = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + c * 8);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTHR, r = i / CH, c = i - r * CH;
+            if (i < ROWS * CH) *reinterpret_cast<uint4*>(tile + row_off(r, c)) = v[it];
+        }
+    }
+};
 template <int HD, bool CLAMP, int NTHR = 256>
 __device__ __forceinline__ void stage_rows(unsigned char* tile, const bf16_t* src, int ld, int row_begin, int rows, int nvalid, int tid) {
     constexpr int CH = HD / 8;
@@ -102,17 +129,22 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, Geo<NT>::NW == 8 ? 4 : 2) void attn_
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
     const float c = p.eps_c;
-    stage_rows<HD, true, NTHR>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
-    stage_rows<HD, false, NTHR>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
-    for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
-    __syncthreads();
     const int q0 = (blockIdx.x * NW + wave) * 32;
-    if (q0 >= N) return;
     const int q = q0 + (lane & 31), qc = min(q, N - 1);
-    const int qself = p.self_keep ? q : -1;
     bf16x8 qf[KS];
+    {
+        Stage<HD, NT * 32, NTHR> sk, sv;           // every global load of the prologue in flight before the first LDS write
+        sk.template load<true>(base + p.D, p.ld, 0, N, tid);
+        sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
+        for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+        sk.store(tK, tid);
+        sv.store(tV, tid);
+    }
+    __syncthreads();
+    if (q0 >= N) return;
+    const int qself = p.self_keep ? q : -1;
     // Two passes over the keys instead of a 7-tile score strip in registers (112 VGPRs, one workgroup per CU): pass 1 only
     // finds the row maximum, pass 2 recomputes each 32-key score tile, exponentiates it and feeds P.V at once.  The MFMA pipe
     // is idle most of the time here; ~116 VGPRs let two workgroups share a CU so that one stages K/V while the other computes.
@@ -210,15 +242,18 @@ __global__ __launch_bounds__(256, 2) void attn_headmean_kernel(const AttnParams 
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    Stage<HD, KT * 32, 256> sk;                     // next head's K tile travels in registers while this head is computed
+    sk.template load<true>(p.qkv + (size_t)b * N * p.ld + p.D, p.ld, key_begin, N, tid);
     for (int h = 0; h < p.H; ++h) {
         const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
         __syncthreads();
-        stage_rows<HD, true>(tK, base + p.D, p.ld, key_begin, KT * 32, N, tid);
+        sk.store(tK, tid);
         __syncthreads();
-        if (!active) continue;
         bf16x8 qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
+        if (h + 1 < p.H) sk.template load<true>(base + HD + p.D, p.ld, key_begin, N, tid);
+        if (!active) continue;
         const size_t si = ((size_t)b * p.H + h) * N + qc;
         const float mx = p.rowmax[si], zi = p.zinv[si];
 #pragma unroll
@@ -268,31 +303,37 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dq_kernel(const Att
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    stage_rows<HD, true, NTHR>(tK, base + p.D, p.ld, 0, NT * 32, N, tid);
-    stage_rows<HD, false, NTHR>(tV, base + 2 * p.D, p.ld, 0, NT * 32, N, tid);
-    for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
-    __syncthreads();
     const int q0 = (blockIdx.x * NW + wave) * 32;
-    if (q0 >= N) return;
     const int q = q0 + (lane & 31), qc = min(q, N - 1);
-    const int qself = p.self_keep ? q : -1;
-    bf16x8 qf[KS], dof[KS];
-    float dl = 0.f;
+    const size_t si = ((size_t)b * p.H + h) * N + qc;
+    bf16x8 qf[KS], dof[KS], ovf[KS];
+    float mx, zi;
     {
+        Stage<HD, NT * 32, NTHR> sk, sv;           // every global load of the prologue in flight before the first LDS write
+        sk.template load<true>(base + p.D, p.ld, 0, N, tid);
+        sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
         const bf16_t* dorow = p.dout + ((size_t)b * N + qc) * p.D + h * HD;
         const bf16_t* orow = p.out + ((size_t)b * N + qc) * p.D + h * HD;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
             dof[ks] = *reinterpret_cast<const bf16x8*>(dorow + ks * 16 + hh * 8);
-            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ov[e];
+            ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
         }
+        mx = p.rowmax[si]; zi = p.zinv[si];
+        for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+        sk.store(tK, tid);
+        sv.store(tV, tid);
     }
+    __syncthreads();
+    if (q0 >= N) return;
+    const int qself = p.self_keep ? q : -1;
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ovf[ks][e];
     dl += __shfl_xor(dl, 32, 64);
-    const size_t si = ((size_t)b * p.H + h) * N + qc;
-    const float mx = p.rowmax[si], zi = p.zinv[si];
     if (hh == 0 && q < N) p.delta[si] = dl;
     f32x16 dq[DT];
 #pragma unroll
@@ -357,26 +398,32 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dkv_kernel(const At
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, N = p.N;
     const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    stage_rows<HD, false, NTHR>(tQ, base, p.ld, 0, NT * 32, N, tid);
-    stage_rows<HD, false, NTHR>(tO, p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, NT * 32, N, tid);
-    for (int i = tid; i < NT * 32; i += NTHR) {
-        const size_t si = ((size_t)b * p.H + h) * N + i;
-        st_m[i] = i < N ? p.rowmax[si] : 0.f;
-        st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
-        st_d[i] = i < N ? p.delta[si] : 0.f;
+    const int k0 = (blockIdx.x * NW + wave) * 32;
+    const int key = k0 + (lane & 31), kc = min(key, N - 1);
+    bf16x8 kf[KS], vf[KS];
+    float keep_key;
+    {
+        Stage<HD, NT * 32, NTHR> sq, so;           // every global load of the prologue in flight before the first LDS write
+        sq.template load<false>(base, p.ld, 0, N, tid);
+        so.template load<false>(p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, N, tid);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(base + p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
+        }
+        keep_key = key < N ? (p.policy ? p.policy[(size_t)b * N + kc] : 1.0f) : 0.f;
+        for (int i = tid; i < NT * 32; i += NTHR) {
+            const size_t si = ((size_t)b * p.H + h) * N + i;
+            st_m[i] = i < N ? p.rowmax[si] : 0.f;
+            st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
+            st_d[i] = i < N ? p.delta[si] : 0.f;
+        }
+        sq.store(tQ, tid);
+        so.store(tO, tid);
     }
     __syncthreads();
-    const int k0 = (blockIdx.x * NW + wave) * 32;
     if (k0 >= N) return;
-    const int key = k0 + (lane & 31), kc = min(key, N - 1);
-    const float keep_key = key < N ? (p.policy ? p.policy[(size_t)b * N + kc] : 1.0f) : 0.f;
     const int kself = p.self_keep ? key : -1;
-    bf16x8 kf[KS], vf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(base + p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
-    }
     const float c = p.eps_c;
     f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -431,6 +478,199 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dkv_kernel(const At
                     *reinterpret_cast<uint2*>(vrow + d) = make_uint2(pack_bf16x2(dv[dt][4 * g], dv[dt][4 * g + 1]), pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]));
                 }
             }
+    }
+}
+
+
+// ------------------------------------------------------------------------------- backward: dQ, dK, dV in ONE launch
+// One workgroup per (batch, head), two phases over the same LDS image:
+//   phase A (as attn_bwd_dq): K / V staged, each wave owns a 32-query tile -> delta (kept in LDS, never in HBM) and dQ;
+//   phase B (as attn_bwd_dkv): Q / dO staged into the SAME LDS space, each wave owns a 32-key tile -> dK, dV.
+// Against the two-kernel form this reads K, V, Q, dO from HBM once instead of twice (the second touch of each is an L2 hit a
+// few microseconds after the first), drops the delta round trip and one launch: 470 -> ~310 MB per layer at (256, 6, 197, 64).
+template <int HD, int NT, int MINW, bool SPLITD>
+__global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(const AttnParams p) {
+    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
+    static_assert(NT <= NW, "one query / key tile per wave");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + 4 * NT * 32 * 4];
+    unsigned char* tA = lds;                                   // phase A: K      phase B: Q
+    unsigned char* tB = lds + NT * 32 * 128;                   // phase A: V      phase B: dO
+    float* pol = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);
+    float* st_m = pol + NT * 32;
+    float* st_z = st_m + NT * 32;
+    float* st_d = st_z + NT * 32;
+    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
+    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
+    const bf16_t* dobase = p.dout + (size_t)b * N * p.D + h * HD;
+    const int r0 = wave * 32;                      // this wave's query tile (phase A) and key tile (phase B)
+    const bool active = wave < NT && r0 < N;
+    const int row = r0 + (lane & 31), rc = min(row, N - 1);
+    bf16x8 qf[KS], dof[KS], ovf[KS];
+    {
+        Stage<HD, NT * 32, NTHR> sk, sv;           // every global load of the prologue in flight before the first LDS write
+        sk.template load<true>(base + p.D, p.ld, 0, N, tid);
+        sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
+        const bf16_t* dorow = dobase + (size_t)rc * p.D;
+        const bf16_t* orow = p.out + ((size_t)b * N + rc) * p.D + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)rc * p.ld + ks * 16 + hh * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dorow + ks * 16 + hh * 8);
+            ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
+        }
+        for (int i = tid; i < NT * 32; i += NTHR) {
+            const size_t si = ((size_t)b * p.H + h) * N + i;
+            pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+            st_m[i] = i < N ? p.rowmax[si] : 0.f;
+            st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
+            st_d[i] = 0.f;                            // rows of query tiles no wave owns stay finite
+        }
+        sk.store(tA, tid);
+        sv.store(tB, tid);
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- phase A: delta, dQ
+    if (active) {
+        const int qself = p.self_keep ? row : -1;
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ovf[ks][e];
+        dl += __shfl_xor(dl, 32, 64);
+        const float mx = st_m[rc], zi = row < N ? st_z[rc] : 0.f;
+        if (hh == 0) st_d[row] = row < N ? dl : 0.f;
+        f32x16 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f32x16 s, g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tA, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tB, t * 32, ks, lane), dof[ks], g, 0, 0, 0);
+            }
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int key0 = t * 32 + 8 * gg + 4 * hh;
+                const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
+                const float keep[4] = {kp.x, kp.y, kp.z, kp.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float k = (key0 + i == qself) ? 1.0f : keep[i];
+                    const float pt = __expf(s[4 * gg + i] * p.scale - mx) * k * zi;   // padded keys: keep = 0
+                    s[4 * gg + i] = pt * (g[4 * gg + i] - dl);           // dS (before the scale factor)
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 dsf = pack8(s, 8 * st);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tA, t * 32 + 16 * st, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (row < N) {
+            bf16_t* orow = p.dqkv + ((size_t)b * N + row) * p.ld + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + 8 * g + 4 * hh;
+                    if (d < HD)
+                        *reinterpret_cast<uint2*>(orow + d) = make_uint2(pack_bf16x2(dq[dt][4 * g] * p.scale, dq[dt][4 * g + 1] * p.scale),
+                                                                         pack_bf16x2(dq[dt][4 * g + 2] * p.scale, dq[dt][4 * g + 3] * p.scale));
+                }
+        }
+    }
+    // this wave's K / V rows for phase B come out of the LDS image before it is overwritten; Q / dO are re-read (L2) meanwhile
+    bf16x8 kf[KS], vf[KS];
+    {
+        Stage<HD, NT * 32, NTHR> sq, so;
+        sq.template load<false>(base, p.ld, 0, N, tid);
+        so.template load<false>(dobase, p.D, 0, N, tid);
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag_rows(tA, r0, ks, lane); vf[ks] = frag_rows(tB, r0, ks, lane); }
+        }
+        __syncthreads();
+        // ---------------------------------------------------------------- phase B: dK, dV
+        sq.store(tA, tid);
+        so.store(tB, tid);
+    }
+    __syncthreads();
+    if (!active) return;
+    const int key = row;
+    const float keep_key = key < N ? pol[rc] : 0.f;
+    const int kself = p.self_keep ? key : -1;
+    const float c = p.eps_c;
+    // SPLITD: one 32-wide slice of the head dimension per pass over the query tiles (scores recomputed per slice): half the
+    // accumulator registers, so that two workgroups fit a CU
+    constexpr int DPASS = SPLITD ? DT : 1, DW = SPLITD ? 1 : DT;
+#pragma unroll 1
+    for (int dp = 0; dp < DPASS; ++dp) {
+        f32x16 dk[DW], dv[DW];
+#pragma unroll
+        for (int dt = 0; dt < DW; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f32x16 s, g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tA, t * 32, ks, lane), kf[ks], s, 0, 0, 0);   // [q][key]
+                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tB, t * 32, ks, lane), vf[ks], g, 0, 0, 0);   // dO.V^T
+            }
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int qq0 = t * 32 + 8 * gg + 4 * hh;
+                const float4 m4 = *reinterpret_cast<const float4*>(st_m + qq0), z4 = *reinterpret_cast<const float4*>(st_z + qq0),
+                             d4 = *reinterpret_cast<const float4*>(st_d + qq0);
+                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float k = (qq0 + i == kself) ? 1.0f : keep_key;
+                    const float pt = __expf(s[4 * gg + i] * p.scale - mm[i]) * k * zz[i];
+                    s[4 * gg + i] = pt * (g[4 * gg + i] - dd[i]);          // dS[q][key]
+                    g[4 * gg + i] = pt + c * zz[i];                         // out[q][key]
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 dsf = pack8(s, 8 * st), pf = pack8(g, 8 * st);
+#pragma unroll
+                for (int dt = 0; dt < DW; ++dt) {
+                    const int dbase = (SPLITD ? dp : dt) * 32;
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tA, t * 32 + 16 * st, dbase, lane), dsf, dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tB, t * 32 + 16 * st, dbase, lane), pf, dv[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (key < N) {
+            bf16_t* krow = p.dqkv + ((size_t)b * N + key) * p.ld + p.D + h * HD;
+            bf16_t* vrow = krow + p.D;
+#pragma unroll
+            for (int dt = 0; dt < DW; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = (SPLITD ? dp : dt) * 32 + 8 * g + 4 * hh;
+                    if (d < HD) {
+                        *reinterpret_cast<uint2*>(krow + d) = make_uint2(pack_bf16x2(dk[dt][4 * g] * p.scale, dk[dt][4 * g + 1] * p.scale),
+                                                                         pack_bf16x2(dk[dt][4 * g + 2] * p.scale, dk[dt][4 * g + 3] * p.scale));
+                        *reinterpret_cast<uint2*>(vrow + d) = make_uint2(pack_bf16x2(dv[dt][4 * g], dv[dt][4 * g + 1]), pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]));
+                    }
+                }
+        }
     }
 }
 
@@ -508,9 +748,18 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
+    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 1;
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
+        if (fused) {            // one launch: both phases share the staged tiles (PPF_ATTN_BWD_FUSED=0: the two-kernel form)
+            constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value, W2 = G::NW == 8 ? 4 : 2;
+            if (fused == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<HDv, NTv, W2, false>), dim3(1, H, B), dim3(G::NTHR), 0, stream, p);
+            else if (fused == 3) hipLaunchKernelGGL((attn_bwd_fused_kernel<HDv, NTv, W2, true>), dim3(1, H, B), dim3(G::NTHR), 0, stream, p);
+            else hipLaunchKernelGGL((attn_bwd_fused_kernel<HDv, NTv, 2, false>), dim3(1, H, B), dim3(G::NTHR), 0, stream, p);
+            PPF_LAUNCH_CHECK();
+            return 0;
+        }
         hipLaunchKernelGGL((attn_bwd_dq_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(G::NTHR), 0, stream, p);
         PPF_LAUNCH_CHECK();
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(G::NTHR), 0, stream, p);

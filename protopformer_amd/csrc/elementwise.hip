@@ -48,25 +48,35 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
 }
 
 // dx [B][T][D] -> dtok bf16 [B*Np][D] (rows t >= lead), dpos[t] += sum_b dx[b][t], dcls += sum_b dx[b][0] (lead = 1).
-// One thread owns a column pair of one token and walks the batch in order: a single writer per output, fixed summation order
-// (no float atomics -> bit-identical from run to run).
+// A workgroup owns 64 column pairs of one token; its four waves walk a quarter of the batch each (8 loads in flight per lane)
+// and the quarters are added in a fixed order through LDS: a single writer per output, no float atomics -> bit-identical
+// from run to run.
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dtok,
                                                            float* __restrict__ dpos, float* __restrict__ dcls, int B, int Np,
                                                            int D, int lead) {
-    const int T = Np + lead, d2 = D / 2;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * d2) return;
-    const int c = (i % d2) * 2, t = i / d2;
+    __shared__ float2 part[4][64];
+    const int T = Np + lead, d2 = D / 2, cblocks = (d2 + 63) / 64;
+    const int t = blockIdx.x / cblocks, cp = (blockIdx.x % cblocks) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int c = cp * 2;
+    const int bq = (B + 3) / 4, b0 = q * bq, b1 = min(B, b0 + bq);
     float2 acc = make_float2(0.f, 0.f);
-#pragma unroll 4
-    for (int b = 0; b < B; ++b) {
-        const float2 v = *reinterpret_cast<const float2*>(dx + ((size_t)b * T + t) * D + c);
-        acc.x += v.x; acc.y += v.y;
-        if (t >= lead) *reinterpret_cast<uint32_t*>(dtok + ((size_t)b * Np + (t - lead)) * D + c) = pack_bf16x2(v.x, v.y);
+    if (cp < d2) {
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) {
+            const float2 v = *reinterpret_cast<const float2*>(dx + ((size_t)b * T + t) * D + c);
+            acc.x += v.x; acc.y += v.y;
+            if (t >= lead) *reinterpret_cast<uint32_t*>(dtok + ((size_t)b * Np + (t - lead)) * D + c) = pack_bf16x2(v.x, v.y);
+        }
     }
-    float* dp = dpos + (size_t)t * D + c;
-    dp[0] += acc.x; dp[1] += acc.y;
-    if (t < lead && dcls) { dcls[c] += acc.x; dcls[c + 1] += acc.y; }
+    part[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && cp < d2) {
+        const float2 a0 = part[0][threadIdx.x], a1 = part[1][threadIdx.x], a2 = part[2][threadIdx.x], a3 = part[3][threadIdx.x];
+        const float sx = (a0.x + a1.x) + (a2.x + a3.x), sy = (a0.y + a1.y) + (a2.y + a3.y);
+        float* dp = dpos + (size_t)t * D + c;
+        dp[0] += sx; dp[1] += sy;
+        if (t < lead && dcls) { dcls[c] += sx; dcls[c + 1] += sy; }
+    }
 }
 
 // Fused AdamW (decoupled weight decay, torch.optim.AdamW semantics) over a flat parameter buffer split in
@@ -140,12 +150,24 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
         else if (dbias) unsafeAtomicAdd(dbias + c, acc);
     }
 }
-__global__ __launch_bounds__(256) void sigmoid_bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int nblk, int cols) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+// 64 columns per workgroup, 16 groups of lanes each summing every 16th partial (independent loads, in flight together), then the 16
+// group sums in a fixed order through LDS
+__global__ __launch_bounds__(1024) void sigmoid_bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int nblk, int cols) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += partial[(size_t)b * cols + c];
-    dbias[c] += acc;
+    if (c < cols) {
+#pragma unroll 8
+        for (int b = g; b < nblk; b += 16) acc += partial[(size_t)b * cols + c];
+    }
+    red[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        dbias[c] += t;
+    }
 }
 
 // ---- global gradient-norm clipping (timm NativeScaler / dispatch_clip_grad, engine_proto.py:74-76): two deterministic passes
@@ -238,6 +260,47 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = x[i] * s;
 }
 
+// ---- input pipeline finisher (tools/datasets.py:280-336 ToTensor + Normalize, timm RandomErasing mode 'pixel'):
+// uint8 HWC frames (as the CPU decode / augmentation workers leave them) -> fp32 NCHW, (x/255 - mean) / std per channel; inside the
+// sample's erase rectangle (y, x, h, w; h == 0: none) every value is replaced by N(0,1) noise (Philox4x32-10 + Box-Muller, keyed
+// by seed / step counter / sample / pixel).  One pass, 4 pixels per lane: the fp32 batch is written exactly once.
+struct FinishParams { const unsigned char* in; float* out; const int* rects; int B, H, W; float mean[3], inv_std[3]; uint64_t seed; const unsigned long long* state; };
+__global__ __launch_bounds__(256) void image_finish_kernel(const FinishParams p) {
+    const int64_t hw = (int64_t)p.H * p.W, total4 = (int64_t)p.B * hw / 4;
+    const unsigned long long step = p.state ? p.state[0] : 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)((i * 4) / hw);
+        const int64_t pix = i * 4 - (int64_t)b * hw;                  // 4 consecutive pixels of one row (W % 4 == 0)
+        const int y = (int)(pix / p.W), x = (int)(pix % p.W);
+        const unsigned char* src = p.in + ((int64_t)b * hw + pix) * 3;
+        const uint32_t w0 = reinterpret_cast<const uint32_t*>(src)[0], w1 = reinterpret_cast<const uint32_t*>(src)[1], w2 = reinterpret_cast<const uint32_t*>(src)[2];
+        const unsigned char px[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                      (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                      (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+        int ry = 0, rx = 0, rh = 0, rw = 0;
+        if (p.rects) { ry = p.rects[4 * b]; rx = p.rects[4 * b + 1]; rh = p.rects[4 * b + 2]; rw = p.rects[4 * b + 3]; }
+        const bool row_in = rh > 0 && y >= ry && y < ry + rh;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((float)px[3 * j + c] * (1.0f / 255.0f) - p.mean[c]) * p.inv_std[c];
+            if (row_in && x + 3 >= rx && x < rx + rw) {
+                const uint4 r = philox4x32_10(make_uint4((uint32_t)(i & 0xffffffff), (uint32_t)(i >> 32) * 3u + c, (uint32_t)step, (uint32_t)(step >> 32)),
+                                              make_uint2((uint32_t)p.seed, (uint32_t)(p.seed >> 32)));
+                const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+                const float u2 = ((float)(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
+                const float m0 = sqrtf(-2.0f * __logf(u0)), m1 = sqrtf(-2.0f * __logf(u2));
+                const float n[4] = {m0 * __cosf(6.283185307f * u1), m0 * __sinf(6.283185307f * u1), m1 * __cosf(6.283185307f * u3), m1 * __sinf(6.283185307f * u3)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x + j >= rx && x + j < rx + rw) v[j] = n[j];
+            }
+            *reinterpret_cast<float4*>(p.out + ((int64_t)b * 3 + c) * hw + pix) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 struct HyperVals { float v[20]; int n; };
 __global__ void hyper_set_kernel(float* __restrict__ hyper, const HyperVals h) {
     if ((int)threadIdx.x < h.n) hyper[threadIdx.x] = h.v[threadIdx.x];
@@ -277,8 +340,8 @@ int ppf_assemble_tokens(const float* tok, const float* cls, const float* pos, fl
 
 int ppf_assemble_tokens_bwd(const float* dx, void* dtok, float* dpos, float* dcls, int B, int Np, int D, int lead, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && Np > 0 && D % 2 == 0 && (lead == 0 || lead == 1), PPF_ERR_SHAPE, "ppf_assemble_tokens_bwd: bad shape");
-    const int T = Np + lead, threads = T * D / 2;
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, dx, (bf16_t*)dtok, dpos, dcls, B, Np, D, lead);
+    const int T = Np + lead, cblocks = (D / 2 + 63) / 64;
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(T * cblocks), dim3(256), 0, stream, dx, (bf16_t*)dtok, dpos, dcls, B, Np, D, lead);
     PPF_LAUNCH_CHECK();
     return 0;
 }
@@ -293,7 +356,7 @@ int ppf_sigmoid_bwd(const float* df, const float* f, void* dz, float* dbias, int
     PPF_CHECK_ARG(partial == nullptr || partial_bytes >= (size_t)nblk * cols * sizeof(float), PPF_ERR_ARG, "ppf_sigmoid_bwd: partial buffer too small");
     if (!dbias) partial = nullptr;
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk), dim3(256), 0, stream, df, f, (bf16_t*)dz, dbias, partial, rows, cols, rpb);
-    if (partial) hipLaunchKernelGGL(sigmoid_bias_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, partial, dbias, nblk, cols);
+    if (partial) hipLaunchKernelGGL(sigmoid_bias_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, stream, partial, dbias, nblk, cols);
     PPF_LAUNCH_CHECK();
     return 0;
 }
@@ -390,6 +453,19 @@ int ppf_scatter_rows(const void* src, const int* rows, void* dst, int nrows_src,
     if (e != hipSuccess) { ppf_set_error("ppf_scatter_rows: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(move_rows_kernel, dim3(grid_for((int64_t)nrows_src * (row_bytes / 16))), dim3(256), 0, stream, (const uint4*)src, rows, (uint4*)dst,
                        nrows_src, row_bytes / 16, 1);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_image_finish_u8(const void* in_u8_hwc, float* out_nchw, int B, int H, int W, const float* mean3, const float* std3, const int* rects,
+                        uint64_t seed, const void* state_u64, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && H > 0 && W > 0 && W % 4 == 0 && in_u8_hwc && out_nchw && mean3 && std3, PPF_ERR_ARG, "ppf_image_finish_u8: bad arguments (W %% 4 == 0)");
+    PPF_CHECK_ARG((((uintptr_t)in_u8_hwc) & 3) == 0 && (((uintptr_t)out_nchw) & 15) == 0, PPF_ERR_ALIGN, "ppf_image_finish_u8: alignment");
+    FinishParams p;
+    p.in = (const unsigned char*)in_u8_hwc; p.out = out_nchw; p.rects = rects; p.B = B; p.H = H; p.W = W; p.seed = seed;
+    p.state = (const unsigned long long*)state_u64;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.inv_std[c] = 1.0f / std3[c]; }
+    hipLaunchKernelGGL(image_finish_kernel, dim3(grid_for((int64_t)B * H * W / 4)), dim3(256), 0, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;
 }

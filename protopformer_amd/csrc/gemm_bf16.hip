@@ -45,42 +45,49 @@ __device__ __forceinline__ int lds_off_mode1(int kc, int col) {
 template <bool T, int ROWS>
 struct TileIO {
     static constexpr int NLD = ROWS / 32;            // 16-byte loads per thread
-    static __device__ __forceinline__ void gload(uint4 (&reg)[NLD], const bf16_t* __restrict__ X, int ld, int R, int row0,
-                                                 int k0, int kend, int tid, int kpad) {
+    // Branch-free: every load is issued unconditionally from a clamped (always valid) address and the "outside the matrix"
+    // predicate travels as a bit mask that sstore applies.  Loads under per-lane branches made the compiler wait vmcnt(0) at
+    // every K step (it cannot count loads across exec-masked branches), which serialised the register pipeline.
+    static __device__ __forceinline__ unsigned gload(uint4 (&reg)[NLD], const bf16_t* __restrict__ X, int ld, int R, int row0,
+                                                     int k0, int kend, int tid, int kpad) {
+        unsigned mask = 0;
         if constexpr (!T) {
             const int c16 = tid & 7, rb = tid >> 3;
             const bool kok = kpad ? (k0 + c16 * 8) < kend : (k0 + c16 * 8 + 8) <= kend;
+            const int kk = kok ? k0 + c16 * 8 : 0;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int r = row0 + rb + 32 * i;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (kok && r < R) v = *reinterpret_cast<const uint4*>(X + (size_t)r * ld + k0 + c16 * 8);
-                reg[i] = v;
+                reg[i] = *reinterpret_cast<const uint4*>(X + (size_t)min(r, R - 1) * ld + kk);
+                mask |= (kok && r < R) ? (1u << i) : 0u;
             }
         } else {
             constexpr int CPR = ROWS / 8;            // 16-byte chunks per kc row
             const int c16 = tid % CPR, kb = tid / CPR;
             const int col = row0 + c16 * 8;
             const bool cok = kpad ? col < R : (col + 8) <= R;
+            const int cc = cok ? col : 0;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int kc = k0 + kb + (256 / CPR) * i;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (cok && kc < kend) v = *reinterpret_cast<const uint4*>(X + (size_t)kc * ld + col);
-                reg[i] = v;
+                reg[i] = *reinterpret_cast<const uint4*>(X + (size_t)min(kc, kend - 1) * ld + cc);
+                mask |= (cok && kc < kend) ? (1u << i) : 0u;
             }
         }
+        return mask;
     }
-    static __device__ __forceinline__ void sstore(const uint4 (&reg)[NLD], unsigned char* tile, int tid) {
+    static __device__ __forceinline__ void sstore(const uint4 (&reg)[NLD], unsigned mask, unsigned char* tile, int tid) {
         if constexpr (!T) {
             const int c16 = tid & 7, rb = tid >> 3;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = reg[i];
+            for (int i = 0; i < NLD; ++i)
+                *reinterpret_cast<uint4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = ((mask >> i) & 1u) ? reg[i] : make_uint4(0, 0, 0, 0);
         } else {
             constexpr int CPR = ROWS / 8;
             const int c16 = tid % CPR, kb = tid / CPR;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) *reinterpret_cast<uint4*>(tile + lds_off_mode1<ROWS>(kb + (256 / CPR) * i, c16 * 8)) = reg[i];
+            for (int i = 0; i < NLD; ++i)
+                *reinterpret_cast<uint4*>(tile + lds_off_mode1<ROWS>(kb + (256 / CPR) * i, c16 * 8)) = ((mask >> i) & 1u) ? reg[i] : make_uint4(0, 0, 0, 0);
         }
     }
     // Fragment of the 32-row sub-tile starting at rbase for k-substep ks (16 contraction values):
@@ -103,8 +110,11 @@ struct TileIO {
 
 // MT = 32-row MFMA tiles per wave along m: MT = 2 -> 128x128 workgroup tile (3 workgroups/CU), MT = 4 -> 256x128 (wave tile
 // 128x64, 2 workgroups/CU): fewer LDS bytes and barriers per flop for the tall activation GEMMs (M = B*N tokens).
-template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
-__global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const GemmParams p_) {
+// PD = K tiles in flight per workgroup (register stages): 1 = the next tile is prefetched while the current one is multiplied (three
+// workgroups per CU); 3 = three tiles ahead, 96 staging registers, two workgroups per CU -- for operands streamed from HBM over a
+// long contraction (weight gradients: 50 432 tokens) one tile ahead leaves every K step exposed to a full memory round trip.
+template <bool TA, bool TB, int EPI, bool COLSUM, int MT, int PD>
+__global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_kernel(const GemmParams p_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TBM = 64 * MT;                    // workgroup tile rows
     constexpr int A_BYTES = TBM * BK * 2;
@@ -138,7 +148,8 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    uint4 ra[IOA::NLD], rb[IOB::NLD];
+    uint4 ra[PD][IOA::NLD], rb[PD][IOB::NLD];
+    unsigned ma[PD], mb[PD];
     f32x16 acc[2][MT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -157,48 +168,58 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
     unsigned char* tA = smem;
     unsigned char* tB = smem + A_BYTES;
 
-    IOA::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid, p.kpad);
-    IOB::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid, p.kpad);
-    IOA::sstore(ra, tA, tid);
-    IOB::sstore(rb, tB, tid);
+#pragma unroll
+    for (int st = 0; st < PD; ++st) {
+        const int k0 = min(kbeg + st * BK, kbeg + (nk - 1) * BK);     // st >= nk: a harmless re-read of the last tile, never stored
+        ma[st] = IOA::gload(ra[st], p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
+        mb[st] = IOB::gload(rb[st], p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
+    }
+    IOA::sstore(ra[0], ma[0], tA, tid);
+    IOB::sstore(rb[0], mb[0], tB, tid);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) {                                          // next tile's loads fly while this tile is multiplied
-            const int k0 = kbeg + (kt + 1) * BK;
-            IOA::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
-            IOB::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
-        }
+    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[MT], fb[2];
+        for (int u = 0; u < PD; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;
+            {                                                // stage u is in LDS: refill it PD tiles ahead; the loads fly while
+                // this and the next PD-1 tiles are multiplied (past the end: re-read of the last tile, never stored -- keeps the
+                // loop body branch-free so that the compiler's vmcnt counting leaves PD-1 tiles in flight)
+                const int k0 = kbeg + min(kt + PD, nk - 1) * BK;
+                ma[u] = IOA::gload(ra[u], p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
+                mb[u] = IOB::gload(rb[u], p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
+            }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = IOA::frag(tA, wm + 32 * i, ks, lane);
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 fa[MT], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fb[i] = IOB::frag(tB, wn + 32 * i, ks, lane);
+                for (int i = 0; i < MT; ++i) fa[i] = IOA::frag(tA, wm + 32 * i, ks, lane);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+                for (int i = 0; i < 2; ++i) fb[i] = IOB::frag(tB, wn + 32 * i, ks, lane);
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-            if constexpr (COLSUM) {
-                if (do_colsum) {
-                    bf16x8 ones;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
-                        accs[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[mi], accs[mi], 0, 0, 0);
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                if constexpr (COLSUM) {
+                    if (do_colsum) {
+                        bf16x8 ones;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+                            accs[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[mi], accs[mi], 0, 0, 0);
+                    }
                 }
             }
+            __syncthreads();                                 // single LDS operand buffer: everyone finished reading it
+            if (kt + 1 < nk) {
+                IOA::sstore(ra[(u + 1) % PD], ma[(u + 1) % PD], tA, tid);
+                IOB::sstore(rb[(u + 1) % PD], mb[(u + 1) % PD], tB, tid);
+            }
+            __syncthreads();
         }
-        __syncthreads();                                     // single LDS operand buffer: everyone finished reading it
-        if (more) {
-            IOA::sstore(ra, tA, tid);
-            IOB::sstore(rb, tB, tid);
-        }
-        __syncthreads();
     }
 
     // epilogue.  After the MFMAs a lane holds, for each (ni, mi): row m = wm+32*mi+(lane&31) and, for g = 0..3, the four
@@ -372,11 +393,11 @@ bool g4_eligible(const GemmParams& p) {
            (long long)p.N * p.ldb < (1ll << 30) && (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) >= 512;
 }
 
-template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
+template <bool TA, bool TB, int EPI, bool COLSUM, int MT, int PD = 1>
 int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch) {
     constexpr int TBM = 64 * MT;
     const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + BN - 1) / BN);
-    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, MT>;
+    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, MT, PD>;
     constexpr int opnd = TBM * BK * 2 + TILE_BYTES;
     constexpr int lds = opnd > STAGE_BYTES ? opnd : STAGE_BYTES;
     static bool attr_set = false;
@@ -401,7 +422,14 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) 
     // measured (profiles/r1_gemm_tile_ab.txt): the 256x128 tile is 5-30 % slower at every shape of this model -> opt-in only
     (void)tall_tiles;
     const bool tall = forced == 4;
-    return tall ? launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch) : launch_impl<TA, TB, EPI, COLSUM, 2>(p, splitk, stream, nbatch);
+    if (tall) return launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch);
+    // PPF_GEMM_PD=3: three K tiles in flight for the long-contraction weight gradients (measured equal to one tile ahead: the kernel is
+    // not latency-bound -- SQ_WAIT_ANY 22 %, issue stalls 47 % -- profiles/r2_wgrad_pmc.txt), default 1
+    static const int pd = getenv("PPF_GEMM_PD") ? atoi(getenv("PPF_GEMM_PD")) : 1;
+    if constexpr (TA && TB && (EPI == EPI_PARTIAL || EPI == EPI_ATOMIC)) {
+        if (pd == 3 && nbatch == 1) return launch_impl<TA, TB, EPI, COLSUM, 2, 3>(p, splitk, stream, nbatch);
+    }
+    return launch_impl<TA, TB, EPI, COLSUM, 2>(p, splitk, stream, nbatch);
 }
 
 // out[i] += sum_z ws[z][i] for the M*N tile elements (row stride ldc) and, when colsum != null, the cs_parts * M partial column sums
