@@ -33,6 +33,12 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 const char* ppf_last_error(void);
 int ppf_abi_version(void);
 int ppf_device_info(int* cu_count, int* clock_mhz, char* name, int name_len);
+/* stream ordering for the two-lane schedule of the host mirror (weight gradients / head-mean maps / prototype gradients on a side
+ * stream): pooled, timing-disabled events inside the library; one call per dependency.
+ * wait_stream: everything on src so far happens-before later work on dst.  mark / wait_mark: a ticket for "src so far". */
+int ppf_stream_wait_stream(ppf_stream_t dst, ppf_stream_t src);
+int64_t ppf_stream_mark(ppf_stream_t stream);
+int ppf_stream_wait_mark(ppf_stream_t stream, int64_t ticket);
 
 /* ---- dense bf16 MFMA GEMM family: every nn.Linear / 1x1 conv / PatchEmbed conv of the path ----------------------
  * C[m][n] (+)= epi( sum_kc A(m,kc) * B(n,kc) ), fp32 accumulate.
@@ -118,9 +124,14 @@ int ppf_merge3_cast(const float* a, const float* b, const float* cq, void* out, 
 /* ---- attention rollout + token reservation (deit:99-124, 223-234; cait:223-261, 328-339) ------------------------
  * hm [L][B][N][NP] head-mean attention of the rollout layers; kdrop = int(N*N*0.9), kdrop_init = int((N+1)*0.9).
  * lead = 1 (DeiT): row 0 of a_{L-1}..a_0, outputs skip the cls column; lead = 0 (CaiT): init_rows [n_init][B][N+1] are the
- * class-attention rows.  Outputs: cls_attn [B][N-lead], idx [B][k] int32 ascending (topk + sort), policy [B][N-lead+1]. */
+ * class-attention rows.  Outputs: cls_attn [B][N-lead], idx [B][k] int32 ascending (topk + sort), policy [B][N-lead+1].
+ * thr_u32 (optional) [L][B]: the per (layer, sample) discard thresholds from ppf_rollout_threshold -- the exact order statistic
+ * "int(N*N*0.9)-th smallest entry" (deit:108-112) does not depend on the chain, so it can be taken per layer as soon as that layer's
+ * head-mean map exists (off the critical path); NULL: selected inside ppf_rollout. */
+int ppf_rollout_threshold(const float* hm_layer, int B, int N, int NP, int kdrop, void* thr_out_u32, ppf_stream_t stream);
 int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int NP, const float* init_rows, int n_init, int lead,
-                int kdrop, int kdrop_init, float identity, int k, float* cls_attn, int* idx, float* policy, ppf_stream_t stream);
+                int kdrop, int kdrop_init, float identity, int k, const void* thr_u32, float* cls_attn, int* idx, float* policy,
+                ppf_stream_t stream);
 /* topk(k) + ascending sort of indices on given scores [B][n] (protopformer.py:157-158, 273-274) */
 int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, ppf_stream_t stream);
 

@@ -504,6 +504,7 @@ def init_state_dict(cfg: dict, seed: int = 1028) -> SD:
 ARCH_CFGS = {
     "deit_tiny_patch16_224": dict(arch="deit", dim=192, depth=12, heads=3),
     "deit_small_patch16_224": dict(arch="deit", dim=384, depth=12, heads=6),
+    "deit_base_patch16_224": dict(arch="deit", dim=768, depth=12, heads=12),
     "cait_xxs24_224": dict(arch="cait", dim=192, depth=24, heads=4, init_scale=1e-5),
 }
 

@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
 
-# signature spec per entry point: p = device/host pointer, i = int32, l = int64, f = float, s = hipStream_t
+# signature spec per entry point: p = device/host pointer, i = int32, l = int64, L = uint64, f = float, z = size_t, s = hipStream_t
 SIGS = {
     "ppf_gemm_bf16": "pppiiiiiiiiippipipppipf" "pz" "s",
     "ppf_device_info": "pppi",
@@ -26,7 +26,8 @@ SIGS = {
     "ppf_attn_fwd": "ppppp" "iiiii" "i" "s",
     "ppf_attn_headmean": "ppppp" "i" "iiiii" "i" "s",
     "ppf_attn_bwd": "pppppppp" "iiiii" "i" "s",
-    "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "ppp" "s",
+    "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "pppp" "s",
+    "ppf_rollout_threshold": "p" "iiii" "p" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",
     "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
@@ -60,10 +61,14 @@ SIGS = {
     "ppf_memset_zero": "pz" "s",
     "ppf_image_finish_u8": "pp" "iii" "ppp" "Lp" "s",
     "ppf_scale_by_scalar": "ppp" "l" "s",
+    "ppf_stream_wait_stream": "pp",
+    "ppf_stream_wait_mark": "pl",
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
+_FAST = {}                     # name -> (bound function, pointer-argument positions, has trailing stream, arity)
+_stream_override = []          # raw hipStream_t stack: set by the weight-gradient lane while it enqueues on its own stream
 
 
 def lib():
@@ -83,10 +88,13 @@ def lib():
         _lib.ppf_sigmoid_bwd_blocks.argtypes = [ctypes.c_int]
         _lib.ppf_clip_grad_blocks.restype = ctypes.c_int
         _lib.ppf_clip_grad_blocks.argtypes = []
+        _lib.ppf_stream_mark.restype = ctypes.c_int64
+        _lib.ppf_stream_mark.argtypes = [ctypes.c_void_p]
         for name, spec in SIGS.items():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [_CT[c] for c in spec]
+            _FAST[name] = (fn, tuple(i for i, c in enumerate(spec) if c == "p"), spec.endswith("s"), len(spec))
     return _lib
 
 
@@ -99,19 +107,35 @@ def _ptr(x):
 
 
 def stream_ptr():
+    """Raw hipStream_t the next launch goes to: the weight-gradient lane's while it is enqueueing, else torch's current stream."""
+    if _stream_override:
+        return _stream_override[-1]
     return torch.cuda.current_stream().cuda_stream
 
 
+def push_stream(raw):
+    _stream_override.append(raw)
+
+
+def pop_stream():
+    _stream_override.pop()
+
+
 def call(name, *args):
-    """Invoke an entry point on the current torch stream; the stream argument is appended automatically
+    """Invoke an entry point on the current stream (stream_ptr()); the stream argument is appended automatically
     when the signature ends in 's'."""
-    L = lib()
-    spec = SIGS[name]
-    if spec.endswith("s") and len(args) == len(spec) - 1:
+    if _lib is None:
+        lib()
+    fn, ptr_pos, has_stream, arity = _FAST[name]
+    if has_stream and len(args) == arity - 1:
         args = args + (stream_ptr(),)
-    if len(args) != len(spec):
-        raise TypeError(f"{name}: expected {len(spec)} arguments, got {len(args)}")
-    conv = [(_ptr(a) if c in "ps" else a) for a, c in zip(args, spec)]
-    rc = getattr(L, name)(*conv)
+    if len(args) != arity:
+        raise TypeError(f"{name}: expected {arity} arguments, got {len(args)}")
+    a = list(args)
+    for i in ptr_pos:
+        x = a[i]
+        if x is not None and not isinstance(x, int):
+            a[i] = x.data_ptr()
+    rc = fn(*a)
     if rc != 0:
-        raise RuntimeError(f"{name} failed (rc={rc}): {L.ppf_last_error().decode()}")
+        raise RuntimeError(f"{name} failed (rc={rc}): {_lib.ppf_last_error().decode()}")

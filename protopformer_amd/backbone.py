@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, EPI_SIGMOID_F32
 
 LN_EPS = 1e-6
@@ -74,6 +74,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     H = feats.num_heads
     NP = (N + 3) // 4 * 4
     hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
+    thr = torch.empty((max(reserve_layer, 1), B), dtype=torch.int32, device=x.device)       # rollout discard thresholds per (layer, sample)
     if compact is None:
         compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
     policy = None
@@ -85,7 +86,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     for i, blk in enumerate(feats.blocks):
         if i == reserve_layer:
             lane.join()
-            cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1)
+            cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if reserve_layer > 0 else None)
             if compact:
                 rows = ops.reserved_rows_map(idx, N)
                 x = ops.gather_rows(x, rows)
@@ -97,8 +98,10 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         if i < reserve_layer:
             # only the rollout at `reserve_layer` consumes the head-mean maps: recompute them on the side stream, under the
             # rest of this block
-            lane.submit(lambda qkv=qkv, rowmax=rowmax, zinv=zinv, i=i: ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy,
-                                                                                        self_keep=True, out=hm[i]), (qkv, rowmax, zinv, hm))
+            def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i):
+                ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
+                ops.rollout_threshold(hm[i], thr[i], N)            # the rollout's order statistic of this layer, off the critical path
+            lane.submit(side, (qkv, rowmax, zinv, hm, thr))
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
         n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
@@ -140,41 +143,47 @@ class WgradLane:
     """Second HIP stream for the weight-gradient GEMMs.  dW = dy^T x is off the critical path of backward (only the
     optimizer consumes it), and the dgrad / LayerNorm / attention kernels of the chain rarely fill all 256 CUs, so the
     wgrads run concurrently with them.  Hazards: a wgrad reads tensors produced on the main stream (the lane waits for the
-    main stream before each launch), temporaries may be freed while the lane still reads them (record_stream), and the
-    in-place bf16 gradient buffer is overwritten by the next LayerNorm backward (before_overwrite).  PPF_WGRAD_STREAM=0
-    runs everything on the main stream."""
+    main stream before each launch), temporaries may be freed while the lane still reads them (they are held until the next
+    join), and the in-place bf16 gradient buffer is overwritten by the next LayerNorm backward (before_overwrite).
+    Ordering goes through the library's pooled events (ppf_stream_wait_stream / _mark / _wait_mark): one C call per dependency;
+    the functions submitted here must not allocate torch memory (they run with torch's current stream unchanged and only the
+    library's launch stream redirected).  PPF_WGRAD_STREAM=0 runs everything on the main stream."""
 
     def __init__(self, device):
         self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
         self.stream = torch.cuda.Stream(device=device) if self.enabled else None
+        self.raw = self.stream.cuda_stream if self.enabled else None
         self.last_read = {}
-        self.held = []              # while a step is being captured: tensors the lane reads, kept alive until the next join()
+        self.held = []              # tensors the lane reads, kept alive (so their memory is not reused) until the next join()
+        self._disabled_tags = {k[len("PPF_LANE_"):] for k, v in os.environ.items() if k.startswith("PPF_LANE_") and v == "0"}
 
     def submit(self, fn, reads, tag=None):
-        if not self.enabled or (tag is not None and os.environ.get("PPF_LANE_" + tag, "1") == "0"):
+        if not self.enabled or (tag is not None and tag in self._disabled_tags):
             fn()
             return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        L = _lib.lib()
+        if L.ppf_stream_wait_stream(self.raw, _lib.stream_ptr()):
+            raise RuntimeError(L.ppf_last_error().decode())
+        _lib.push_stream(self.raw)
+        try:
             fn()
-        done = torch.cuda.Event()
-        done.record(self.stream)
-        capturing = torch.cuda.is_current_stream_capturing()
+        finally:
+            _lib.pop_stream()
+        ticket = L.ppf_stream_mark(self.raw)
+        if ticket < 0:
+            raise RuntimeError(L.ppf_last_error().decode())
         for t in reads:
-            if capturing:
-                self.held.append(t)           # record_stream is not capture-safe: keep the block allocated until the lane is joined
-            else:
-                t.record_stream(self.stream)
-            self.last_read[t.data_ptr()] = done
+            self.held.append(t)
+            self.last_read[t.data_ptr()] = ticket
 
     def before_overwrite(self, t):
-        ev = self.last_read.pop(t.data_ptr(), None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        ticket = self.last_read.pop(t.data_ptr(), None)
+        if ticket is not None:
+            _lib.call("ppf_stream_wait_mark", _lib.stream_ptr(), ticket)
 
     def join(self):
         if self.enabled:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            _lib.call("ppf_stream_wait_stream", _lib.stream_ptr(), self.raw)
         self.last_read.clear()
         self.held.clear()
 

@@ -129,12 +129,15 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     NP = (N + 3) // 4 * 4
     depth = len(feats.blocks)
     hm = torch.empty((depth, B, N, NP), dtype=torch.float32, device=x.device)
+    thr = torch.empty((depth, B), dtype=torch.int32, device=x.device)          # rollout discard thresholds per (layer, sample)
+    lane = wgrad_lane(store)
     layers = []
     x = x.reshape(M, D)
     for i, blk in enumerate(feats.blocks):
         n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, prob, a16 = _th_attention_fwd(blk, qkv, B, H, N, D, hm[i])
+        lane.submit(lambda i=i: ops.rollout_threshold(hm[i], thr[i], N), (hm, thr))      # the rollout's order statistic, off the critical path
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N,
@@ -158,7 +161,8 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     for j, blk in enumerate(feats.blocks_token_only):
         if j == reserve_layer:
             init_rows = torch.stack(rowmeans).contiguous()                       # class-attention rows produced so far (cait:249-251)
-            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows)
+            lane.join()
+            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows, thr=thr)
         u = torch.cat([cls.reshape(B, 1, D), xt], dim=1).reshape(B * N1, D)
         n, mean1, rstd1 = ops.layernorm_fwd(u, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         kk = ops.gemm(n, store.w16(blk.attn.k.weight), epi=EPI_BF16, bias=blk.attn.k.bias)
@@ -180,6 +184,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
             ca_layers.append(dict(u=u, n=n, mean1=mean1, rstd1=rstd1, q=qq, k=kk, v=vv, attn=attn, zinv=zinv, out=out, cls=cls, cls1=cls1,
                                   n2=n2, mean2=mean2, rstd2=rstd2, h=h, g=g, raw1=raw1, raw2=raw2, policy=policy))
         cls = cls2
+    lane.join()
     u_out = torch.cat([cls.reshape(B, 1, D), xt], dim=1)
     return u_out, cls_attn, idx, dict(sa=layers, ca=ca_layers)
 

@@ -41,14 +41,37 @@ __device__ __forceinline__ int lds_off_mode1(int kc, int col) {
     return kc * (ROWS * 2) + ((((col >> 5) ^ (kc & 3))) << 6) + ((col & 31) << 1);
 }
 
+// 16-byte global load the compiler does not track (inline asm): with ordinary loads hipcc re-derives the outstanding-load count
+// at the loop header of the register pipeline and waits vmcnt(2) before every refill, draining the pipeline each K step.  The
+// consumer waits by hand (gemm_vmwait<N>) right before the registers are stored to LDS.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));       // a native 128-bit register tuple (inline-asm operand)
+__device__ __forceinline__ u32x4 gload_async(const void* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// The wait names the registers it guards as in/out operands: everything that reads them (the zero-fill select, ds_write) is then
+// data-dependent on the wait and cannot be scheduled above it.
+template <int N>
+__device__ __forceinline__ void gemm_vmwait(u32x4 (&a)[4], u32x4 (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gemm_vmwait_all() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // Operand tile of ROWS rows (m or n) x 64 contraction values, staged global -> registers -> LDS by 256 threads.
-template <bool T, int ROWS>
+template <bool T, int ROWS, bool ASYNC = false>
 struct TileIO {
     static constexpr int NLD = ROWS / 32;            // 16-byte loads per thread
     // Branch-free: every load is issued unconditionally from a clamped (always valid) address and the "outside the matrix"
     // predicate travels as a bit mask that sstore applies.  Loads under per-lane branches made the compiler wait vmcnt(0) at
     // every K step (it cannot count loads across exec-masked branches), which serialised the register pipeline.
-    static __device__ __forceinline__ unsigned gload(uint4 (&reg)[NLD], const bf16_t* __restrict__ X, int ld, int R, int row0,
+    static __device__ __forceinline__ unsigned gload(u32x4 (&reg)[NLD], const bf16_t* __restrict__ X, int ld, int R, int row0,
                                                      int k0, int kend, int tid, int kpad) {
         unsigned mask = 0;
         if constexpr (!T) {
@@ -58,7 +81,8 @@ struct TileIO {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int r = row0 + rb + 32 * i;
-                reg[i] = *reinterpret_cast<const uint4*>(X + (size_t)min(r, R - 1) * ld + kk);
+                const bf16_t* src = X + (size_t)min(r, R - 1) * ld + kk;
+                if constexpr (ASYNC) reg[i] = gload_async(src); else reg[i] = *reinterpret_cast<const u32x4*>(src);
                 mask |= (kok && r < R) ? (1u << i) : 0u;
             }
         } else {
@@ -70,24 +94,26 @@ struct TileIO {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int kc = k0 + kb + (256 / CPR) * i;
-                reg[i] = *reinterpret_cast<const uint4*>(X + (size_t)min(kc, kend - 1) * ld + cc);
+                const bf16_t* src = X + (size_t)min(kc, kend - 1) * ld + cc;
+                if constexpr (ASYNC) reg[i] = gload_async(src); else reg[i] = *reinterpret_cast<const u32x4*>(src);
                 mask |= (cok && kc < kend) ? (1u << i) : 0u;
             }
         }
         return mask;
     }
-    static __device__ __forceinline__ void sstore(const uint4 (&reg)[NLD], unsigned mask, unsigned char* tile, int tid) {
+    static __device__ __forceinline__ void sstore(const u32x4 (&reg)[NLD], unsigned mask, unsigned char* tile, int tid) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
         if constexpr (!T) {
             const int c16 = tid & 7, rb = tid >> 3;
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
-                *reinterpret_cast<uint4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = ((mask >> i) & 1u) ? reg[i] : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<u32x4*>(tile + lds_off_mode0(rb + 32 * i, c16)) = ((mask >> i) & 1u) ? reg[i] : zero;
         } else {
             constexpr int CPR = ROWS / 8;
             const int c16 = tid % CPR, kb = tid / CPR;
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
-                *reinterpret_cast<uint4*>(tile + lds_off_mode1<ROWS>(kb + (256 / CPR) * i, c16 * 8)) = ((mask >> i) & 1u) ? reg[i] : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<u32x4*>(tile + lds_off_mode1<ROWS>(kb + (256 / CPR) * i, c16 * 8)) = ((mask >> i) & 1u) ? reg[i] : zero;
         }
     }
     // Fragment of the 32-row sub-tile starting at rbase for k-substep ks (16 contraction values):
@@ -118,8 +144,11 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TBM = 64 * MT;                    // workgroup tile rows
     constexpr int A_BYTES = TBM * BK * 2;
-    using IOA = TileIO<TA, TBM>;
-    using IOB = TileIO<TB, BN>;
+    constexpr bool ASYNC = PD > 1;                  // the deeper register pipeline counts its loads by hand
+    using IOA = TileIO<TA, TBM, ASYNC>;
+    using IOB = TileIO<TB, BN, ASYNC>;
+    constexpr int LPS = IOA::NLD + IOB::NLD;        // loads per stage and thread
+    static_assert(!ASYNC || (IOA::NLD == 4 && IOB::NLD == 4), "the hand-counted pipeline is written for 128x128 tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * (32 * MT), wn = (wave >> 1) * 64;
 
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    uint4 ra[PD][IOA::NLD], rb[PD][IOB::NLD];
+    u32x4 ra[PD][IOA::NLD], rb[PD][IOB::NLD];
     unsigned ma[PD], mb[PD];
     f32x16 acc[2][MT];
 #pragma unroll
@@ -174,6 +203,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
         ma[st] = IOA::gload(ra[st], p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
         mb[st] = IOB::gload(rb[st], p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
     }
+    if constexpr (ASYNC) gemm_vmwait<(PD - 1) * LPS>(ra[0], rb[0]);
     IOA::sstore(ra[0], ma[0], tA, tid);
     IOB::sstore(rb[0], mb[0], tB, tid);
     __syncthreads();
@@ -214,6 +244,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
                 }
             }
             __syncthreads();                                 // single LDS operand buffer: everyone finished reading it
+            if constexpr (ASYNC) gemm_vmwait<(PD - 1) * LPS>(ra[(u + 1) % PD], rb[(u + 1) % PD]);      // the oldest stage has landed; PD-1 stay in flight
             if (kt + 1 < nk) {
                 IOA::sstore(ra[(u + 1) % PD], ma[(u + 1) % PD], tA, tid);
                 IOB::sstore(rb[(u + 1) % PD], mb[(u + 1) % PD], tB, tid);
@@ -222,6 +253,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
         }
     }
 
+    if constexpr (ASYNC) gemm_vmwait_all<0>();       // refills past the end are still in flight: retire them before the epilogue's loads
     // epilogue.  After the MFMAs a lane holds, for each (ni, mi): row m = wm+32*mi+(lane&31) and, for g = 0..3, the four
     // consecutive columns n = wn+32*ni+8*g+4*(lane>>5).. (acc regs 4g..4g+3): row-strided 8/16-byte pieces.  Each wave
     // therefore transposes its accumulators through a private LDS strip (32 rows x 64 fp32 at a time) so that 16

@@ -29,6 +29,7 @@ struct RolloutParams {
     int kdrop, kdrop_init;   // int(N*N*ratio), int((N+1)*ratio): computed by the host in double like the reference
     float identity;
     int k;
+    const uint32_t* thr;     // optional [L][B]: per (layer, sample) discard thresholds computed ahead by rollout_threshold_kernel
     float* cls_attn;         // [B][Nk]
     int* idx;                // [B][k] ascending
     float* policy;           // [B][1+Nk]
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(NTHR) void rollout_kernel(const RolloutParams p) {
             }
         }
         uint32_t thr = 0;
-        if (kdrop > 0) thr = radix_select<RPW * CPL>(v, kdrop, hist, misc);
+        if (kdrop > 0) thr = p.thr ? p.thr[(size_t)l * p.B + b] : radix_select<RPW * CPL>(v, kdrop, hist, misc);
         float colacc[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) colacc[c] = 0.f;
@@ -212,6 +213,30 @@ __global__ __launch_bounds__(NTHR) void rollout_kernel(const RolloutParams p) {
     if (tid == 0) p.policy[(size_t)b * (Nk + 1)] = 1.0f;
 }
 
+// The discard threshold of ONE layer's head-mean map per sample (the radix select is 90 % of the rollout's time and does not depend
+// on the chain): launched per layer right behind that layer's attn_headmean on the side stream, so that the rollout at the
+// reservation layer -- on the critical path -- is left with the row-vector chain only.  Same select, same key: identical results.
+__global__ __launch_bounds__(NTHR) void rollout_threshold_kernel(const float* __restrict__ f_layer, int N, int NP, int kdrop, uint32_t* __restrict__ thr_out) {
+    __shared__ uint32_t hist[HCOPIES * HSTRIDE];
+    __shared__ uint32_t misc[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const float* f = f_layer + (size_t)b * N * NP;
+    float v[RPW * CPL];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = wave + NWAVE * i;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int col = lane + 64 * c;
+            v[i * CPL + c] = (row < N && col < N) ? f[(size_t)row * NP + col] : INFINITY;
+        }
+    }
+    const uint32_t thr = kdrop > 0 ? radix_select<RPW * CPL>(v, kdrop, hist, misc) : 0u;
+    if (tid == 0) thr_out[b] = thr;
+}
+
 // Standalone top-k + ascending index sort (protopformer.py:157-158, 273-274) for callers that only hold the scores.
 __global__ __launch_bounds__(256) void topk_sorted_kernel(const float* scores, int n, int k, int* idx) {
     __shared__ float vals[256];
@@ -248,8 +273,17 @@ int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, hipStrea
 // hm: [L][B][N][NP] fp32 head-mean attention of the L rollout layers (layer_stride elements apart).
 // init_rows: null (DeiT, lead=1) or [n_init][B][N+1] head-mean class-attention rows (CaiT, lead=0).
 // Outputs: cls_attn [B][N-lead], idx [B][k] int32 ascending, policy [B][N-lead+1] float {0,1}.
+int ppf_rollout_threshold(const float* hm_layer, int B, int N, int NP, int kdrop, void* thr_out_u32, hipStream_t stream) {
+    PPF_CHECK_ARG(B >= 1 && N >= 2 && N <= 16 * RPW && N <= 64 * CPL - 1 && NP >= N && kdrop >= 0 && kdrop < N * N && hm_layer && thr_out_u32, PPF_ERR_SHAPE,
+                  "ppf_rollout_threshold: bad arguments B=%d N=%d NP=%d kdrop=%d", B, N, NP, kdrop);
+    hipLaunchKernelGGL(rollout_threshold_kernel, dim3(B), dim3(NTHR), 0, stream, hm_layer, N, NP, kdrop, (uint32_t*)thr_out_u32);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
 int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int NP, const float* init_rows, int n_init, int lead,
-                int kdrop, int kdrop_init, float identity, int k, float* cls_attn, int* idx, float* policy, hipStream_t stream) {
+                int kdrop, int kdrop_init, float identity, int k, const void* thr_u32, float* cls_attn, int* idx, float* policy,
+                hipStream_t stream) {
     PPF_CHECK_ARG(L >= 1 && B >= 1 && N >= 2 && N <= 16 * RPW && N <= 64 * CPL - 1 && NP >= N, PPF_ERR_SHAPE, "ppf_rollout: bad shape L=%d B=%d N=%d NP=%d", L, B, N, NP);
     PPF_CHECK_ARG((lead == 1 && init_rows == nullptr) || (lead == 0 && init_rows != nullptr && n_init >= 1), PPF_ERR_ARG,
                   "ppf_rollout: lead=1 needs no init rows, lead=0 needs them");
@@ -258,6 +292,7 @@ int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int 
     RolloutParams p;
     p.hm = hm; p.layer_stride = layer_stride; p.L = L; p.B = B; p.N = N; p.NP = NP; p.init_rows = init_rows; p.n_init = n_init; p.lead = lead;
     p.kdrop = kdrop; p.kdrop_init = kdrop_init; p.identity = identity; p.k = k; p.cls_attn = cls_attn; p.idx = idx; p.policy = policy;
+    p.thr = (const uint32_t*)thr_u32;
     hipLaunchKernelGGL(rollout_kernel, dim3(B), dim3(NTHR), 0, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;

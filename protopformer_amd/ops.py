@@ -18,7 +18,7 @@ _WORKSPACE = {}
 def _workspace(device, nbytes):
     """Reusable split-K scratch, grown on demand: one per (device, stream) -- the weight-gradient lane (backbone.WgradLane)
     runs its GEMMs on a second stream, concurrently with main-stream kernels that also use a workspace."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _lib.stream_ptr())
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
@@ -154,7 +154,13 @@ def attn_bwd(qkv, out, dout, rowmax, zinv, B, H, N, D, policy=None, self_keep=Tr
     return dqkv
 
 
-def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2):
+def rollout_threshold(hm_layer, thr_out, N, discard_ratio=0.9):
+    """thr_out [B] int32 <- per-sample key of the int(N*N*ratio)-th smallest entry of one layer's head-mean map [B, N, NP]."""
+    B, _, NP = hm_layer.shape
+    _lib.call("ppf_rollout_threshold", hm_layer, B, N, NP, int(N * N * discard_ratio), thr_out)
+
+
+def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None):
     """hm: [L,B,N,NP] fp32 head-mean attention. Returns (cls_attn [B,N-lead], idx int32 [B,k] ascending, policy [B,N-lead+1])."""
     _chk(hm, torch.float32)
     NP = hm.shape[-1]
@@ -165,7 +171,7 @@ def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=
     n_init = init_rows.shape[0] if init_rows is not None else 0
     # discard counts in double precision, exactly like the reference's int(numel * ratio)
     kdrop, kdrop_init = int(N * N * discard_ratio), int((N + 1) * discard_ratio)
-    _lib.call("ppf_rollout", hm, B * N * NP, L, B, N, NP, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, cls_attn, idx, policy)
+    _lib.call("ppf_rollout", hm, B * N * NP, L, B, N, NP, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, thr, cls_attn, idx, policy)
     return cls_attn, idx, policy
 
 

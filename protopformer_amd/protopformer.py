@@ -22,7 +22,8 @@ ARCHS = {
     "deit_small_patch16_224": dict(kind="deit", embed_dim=384, depth=12, num_heads=6),
     "deit_base_patch16_224": dict(kind="deit", embed_dim=768, depth=12, num_heads=12),           # deit:315-328
     "cait_xxs24_224": dict(kind="cait", embed_dim=192, depth=24, num_heads=4, init_scale=1e-5),
-    "cait_s24_224": dict(kind="cait", embed_dim=384, depth=24, num_heads=8, init_scale=1e-5),    # cait:379-383, cait_features.py:16
+    # cait_s24_224 (cait:379-383: 8 heads) is NOT offered: csrc/cait.hip keeps all heads of the talking-heads mix in registers and is
+    # specialised for H <= 4 (cait_xxs24 / xs24 shapes); construct_PPNet raises KeyError for it instead of running something else.
 }
 
 

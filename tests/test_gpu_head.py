@@ -56,6 +56,22 @@ def test_rollout_deit_vs_oracle(B, N, L, k):
     _check_topk(idx.cpu().long(), ref, k)
 
 
+def test_rollout_with_precomputed_thresholds_is_identical():
+    """ppf_rollout_threshold per layer (side stream in the model) + ppf_rollout(thr=...) == the monolithic rollout, bit for bit."""
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(21)
+    L, B, N, k = 5, 6, 197, 81
+    fused = torch.softmax(3.0 * torch.randn(L, B, N, N, generator=g), dim=-1)
+    hm = _pad_hm(fused)
+    ref = ops.rollout(hm, L, B, N, k, lead=1)
+    thr = torch.empty((L, B), dtype=torch.int32, device="cuda")
+    for l in range(L):
+        ops.rollout_threshold(hm[l], thr[l], N)
+    got = ops.rollout(hm, L, B, N, k, lead=1, thr=thr)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
 def test_rollout_cait_golden():
     from protopformer_amd import ops
     z = load_npz("ops_real.npz")
