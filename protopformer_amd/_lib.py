@@ -106,11 +106,21 @@ def _ptr(x):
     return x
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # C entry: ~0.2 us (torch.cuda.current_stream() costs ~8 us)
+_dev_index = None
+
+
 def stream_ptr():
-    """Raw hipStream_t the next launch goes to: the weight-gradient lane's while it is enqueueing, else torch's current stream."""
+    """Raw hipStream_t the next launch goes to: the weight-gradient lane's while it is enqueueing, else torch's current stream
+    on this process's device (one process drives one GPU; the device index is read once)."""
+    global _dev_index
     if _stream_override:
         return _stream_override[-1]
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return _raw_stream(_dev_index)
 
 
 def push_stream(raw):

@@ -75,6 +75,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     NP = (N + 3) // 4 * 4
     hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
     thr = torch.empty((max(reserve_layer, 1), B), dtype=torch.int32, device=x.device)       # rollout discard thresholds per (layer, sample)
+    side_thr = reserve_layer > 0 and os.environ.get("PPF_ROLLOUT_SIDE", "1") != "0"
     if compact is None:
         compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
     policy = None
@@ -86,7 +87,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     for i, blk in enumerate(feats.blocks):
         if i == reserve_layer:
             lane.join()
-            cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if reserve_layer > 0 else None)
+            cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None)
             if compact:
                 rows = ops.reserved_rows_map(idx, N)
                 x = ops.gather_rows(x, rows)
@@ -100,7 +101,8 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
             # rest of this block
             def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i):
                 ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
-                ops.rollout_threshold(hm[i], thr[i], N)            # the rollout's order statistic of this layer, off the critical path
+                if side_thr:
+                    ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
             lane.submit(side, (qkv, rowmax, zinv, hm, thr))
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)

@@ -1,3 +1,2 @@
 #!/bin/bash
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -4
-timeout 1500 python scripts/gpu/ab_step.py 2 "base:" "nolane:PPF_WGRAD_STREAM=0"
+timeout 2000 python scripts/gpu/ab_step.py 2 "t432:" "t256:PPF_SPLITK_TARGET=256" "t320:PPF_SPLITK_TARGET=320" "t384:PPF_SPLITK_TARGET=384"
