@@ -134,6 +134,63 @@ struct TileIO {
 };
 
 
+// Epilogue of one 32-row x 64-column block that a wave has just transposed into its LDS strip (row pitch STAGE_LD floats):
+// bias / residual / gelu' operands are loaded for the whole block first, then the stores are issued back to back (loads and stores
+// share vmcnt on gfx9).  bf16-output epilogues use 8 columns per lane (16-byte stores, 8 rows per pass), the others 4.
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* stage, int mbase, int nbase, int lane) {
+    if (EpiWide<EPI>::value && ((p.ldc | p.ldaux) & 7) == 0) {          // 16-byte stores need 8-element row pitches
+        const int col = (lane & 7) * 8;
+        const int n = nbase + col;
+        if (n + 8 <= p.N) {
+            const EpiCols8 cc = epi_load_cols8<EPI>(p, n, true);
+            EpiRow8 rr[4];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = mbase + pass * 8 + (lane >> 3);
+                rr[pass] = epi_load_row8<EPI>(p, m, n, m < p.M);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 8 + (lane >> 3);
+                const int m = mbase + r;
+                const float4 a = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
+                const float4 b = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col + 4);
+                if (m < p.M) epi_store8<EPI>(p, m, n, a, b, cc, rr[pass]);
+            }
+        } else if (n < p.N) {                                    // a 4-column remainder at the right edge (N % 8 == 4)
+            const EpiCols cc = epi_load_cols<EPI>(p, n, true);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 8 + (lane >> 3);
+                const int m = mbase + r;
+                if (m < p.M) {
+                    const EpiRow rr = epi_load_row<EPI>(p, m, n, true);
+                    const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
+                    epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr);
+                }
+            }
+        }
+    } else {
+        const int col = (lane & 15) * 4;
+        const int n = nbase + col;
+        const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
+        EpiRow rr[8];
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int m = mbase + pass * 4 + (lane >> 4);
+            rr[pass] = epi_load_row<EPI>(p, m, n, m < p.M && n < p.N);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 4 + (lane >> 4);
+            const int m = mbase + r;
+            const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
+            if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
+        }
+    }
+}
+
 // MT = 32-row MFMA tiles per wave along m: MT = 2 -> 128x128 workgroup tile (3 workgroups/CU), MT = 4 -> 256x128 (wave tile
 // 128x64, 2 workgroups/CU): fewer LDS bytes and barriers per flop for the tall activation GEMMs (M = B*N tokens).
 // PD = K tiles in flight per workgroup (register stages): 1 = the next tile is prefetched while the current one is multiplied (three
@@ -270,22 +327,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
                 *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
                     make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
         __builtin_amdgcn_wave_barrier();                           // keep the compiler from moving reads above the writes
-        const int col = (lane & 15) * 4;
-        const int n = n0 + wn + col;
-        const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
-        EpiRow rr[8];
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int m = m0 + wm + 32 * mi + pass * 4 + (lane >> 4);
-            rr[pass] = epi_load_row<EPI>(p, m, n, m < p.M && n < p.N);
-        }
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 4 + (lane >> 4);
-            const int m = m0 + wm + 32 * mi + r;
-            const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
-            if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
-        }
+        epilogue_rows<EPI>(p, stage, m0 + wm + 32 * mi, n0 + wn, lane);
         __builtin_amdgcn_wave_barrier();                           // the next 32-row block overwrites the strip
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
@@ -380,22 +422,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams 
                 *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
                     make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
         __builtin_amdgcn_wave_barrier();
-        const int col = (lane & 15) * 4;
-        const int n = n0 + wn + col;
-        const EpiCols cc = epi_load_cols<EPI>(p, n, n < p.N);
-        EpiRow rr[8];
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int m = m0 + wm + 32 * mi + pass * 4 + (lane >> 4);
-            rr[pass] = epi_load_row<EPI>(p, m, n, m < p.M && n < p.N);
-        }
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 4 + (lane >> 4);
-            const int m = m0 + wm + 32 * mi + r;
-            const float4 v = *reinterpret_cast<const float4*>(stage + r * STAGE_LD + col);
-            if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v.x, v.y, v.z, v.w, cc, rr[pass]);
-        }
+        epilogue_rows<EPI>(p, stage, m0 + wm + 32 * mi, n0 + wn, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -564,6 +591,26 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
+    // PPF_GEMM_PD_X=d: the register-pipelined 128x128 kernel with d K tiles in flight for the forward (NT) / dgrad (NN) GEMMs
+    static const int pd_x = getenv("PPF_GEMM_PD_X") ? atoi(getenv("PPF_GEMM_PD_X")) : 0;
+    if (pd_x == 2 || pd_x == 3) {
+#define PPF_PDX(TB_, EPI_) (pd_x == 3 ? launch_impl<false, TB_, EPI_, false, 2, 3>(p, 1, stream, 1) : launch_impl<false, TB_, EPI_, false, 2, 2>(p, 1, stream, 1))
+        if (!trans_a && !trans_b) {
+            switch (epi) {
+                case EPI_BF16: return PPF_PDX(false, EPI_BF16);
+                case EPI_GELU: return PPF_PDX(false, EPI_GELU);
+                case EPI_RESID: return PPF_PDX(false, EPI_RESID);
+                default: break;
+            }
+        } else if (!trans_a && trans_b) {
+            switch (epi) {
+                case EPI_BF16: return PPF_PDX(true, EPI_BF16);
+                case EPI_DGELU: return PPF_PDX(true, EPI_DGELU);
+                default: break;
+            }
+        }
+#undef PPF_PDX
+    }
     if (!trans_a && !trans_b) {
         if (nt256_eligible(p, epi)) return launch_nt256(p, epi, stream);
         if (g4_eligible(p)) {

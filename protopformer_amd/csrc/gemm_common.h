@@ -117,6 +117,56 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
     }
 }
 
+// ---- 8-column form of the bf16-output epilogues (EPI_BF16 / EPI_GELU / EPI_DGELU): one 16-byte store per lane instead of two
+// 8-byte ones.  The epilogue of these GEMMs is store-ISSUE bound (knock-out timing, profiles/r2_gemm_knockout.txt: the stores of
+// fc1+GELU cost 73 of 151 us), so halving the number of store instructions is worth more than any main-loop change.
+template <int EPI> struct EpiWide { static constexpr bool value = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU); };
+struct EpiCols8 { float4 bias[2]; };
+struct EpiRow8 { uint4 aux; };
+
+template <int EPI>
+__device__ __forceinline__ EpiCols8 epi_load_cols8(const GemmParams& p, int n0, bool ok) {
+    EpiCols8 c;
+    c.bias[0] = c.bias[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && p.bias) { c.bias[0] = *reinterpret_cast<const float4*>(p.bias + n0); c.bias[1] = *reinterpret_cast<const float4*>(p.bias + n0 + 4); }
+    return c;
+}
+template <int EPI>
+__device__ __forceinline__ EpiRow8 epi_load_row8(const GemmParams& p, int m, int n0, bool ok) {
+    EpiRow8 r;
+    r.aux = make_uint4(0, 0, 0, 0);
+    if constexpr (EPI == EPI_DGELU) {
+        if (ok) {                                 // read once, 10 ms after it was written: streaming load
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n0));
+            r.aux = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    }
+    return r;
+}
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmParams& p, int m, int n0, const float4& a, const float4& b, const EpiCols8& cc, const EpiRow8& rr) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    float v[8] = {a.x * p.alpha + cc.bias[0].x, a.y * p.alpha + cc.bias[0].y, a.z * p.alpha + cc.bias[0].z, a.w * p.alpha + cc.bias[0].w,
+                  b.x * p.alpha + cc.bias[1].x, b.y * p.alpha + cc.bias[1].y, b.z * p.alpha + cc.bias[1].z, b.w * p.alpha + cc.bias[1].w};
+    bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0;
+    if constexpr (EPI == EPI_BF16) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    } else if constexpr (EPI == EPI_GELU) {
+        ppf_float2 g[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gelu_erf_both2(ppf_float2{v[2 * i], v[2 * i + 1]}, g[i], d[i]);
+        // gelu' is not read again before the backward pass: streaming (non-temporal) store, keeps L2 / MALL for the operands
+        const u32x4 dv = {pack_bf16x2(d[0].x, d[0].y), pack_bf16x2(d[1].x, d[1].y), pack_bf16x2(d[2].x, d[2].y), pack_bf16x2(d[3].x, d[3].y)};
+        __builtin_nontemporal_store(dv, reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n0));
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(g[0].x, g[0].y), pack_bf16x2(g[1].x, g[1].y), pack_bf16x2(g[2].x, g[2].y), pack_bf16x2(g[3].x, g[3].y));
+    } else if constexpr (EPI == EPI_DGELU) {
+        const float2 h0 = unpack_bf16x2(rr.aux.x), h1 = unpack_bf16x2(rr.aux.y), h2 = unpack_bf16x2(rr.aux.z), h3 = unpack_bf16x2(rr.aux.w);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0] * h0.x, v[1] * h0.y), pack_bf16x2(v[2] * h1.x, v[3] * h1.y),
+                                                    pack_bf16x2(v[4] * h2.x, v[5] * h2.y), pack_bf16x2(v[6] * h3.x, v[7] * h3.y));
+    }
+}
+
 // 256x256x64 pipelined kernel for contraction-contiguous operands (gemm_nt256.hip)
 bool nt256_eligible(const GemmParams& p, int epi);
 int launch_nt256(const GemmParams& p, int epi, hipStream_t stream);
