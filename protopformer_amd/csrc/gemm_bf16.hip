@@ -362,7 +362,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams 
     const int m0 = (vid / tiles_n) * BM, n0 = (vid % tiles_n) * BN;
     unsigned char* tA = smem;
     unsigned char* tB = smem + TILE_BYTES;
-
     unsigned offA[4], offB[4];
     {
         const int rb = tid >> 3, ch = (tid & 7) ^ ((rb >> 1) & 7);       // rows rb + 32 i share the swizzle

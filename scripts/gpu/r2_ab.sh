@@ -1,2 +1,4 @@
 #!/bin/bash
-timeout 2000 python scripts/gpu/ab_step.py 2 "t432:" "t256:PPF_SPLITK_TARGET=256" "t320:PPF_SPLITK_TARGET=320" "t384:PPF_SPLITK_TARGET=384"
+timeout 300 python scripts/bench_gemm.py 2>&1 | grep "fc1 \|dgelu"
+timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_e2e.py tests/test_gpu_cait.py tests/test_gpu_baseline_configs.py -q 2>&1 | tail -3
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c1-200
