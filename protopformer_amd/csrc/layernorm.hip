@@ -296,36 +296,29 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
 }
 
 // dst[c] += sum over workgroups of partial[wg][which][c], in a fixed order (deterministic; replaces ~1.8M fp32 atomics on 1152
-// addresses per LayerNorm backward).  Two levels: LN_RS slices of the workgroup axis are summed by
-// grid (ceil(D/64), 4 arrays, LN_RS) blocks of 16 row groups x 64 columns into partial2[LN_RS][4][D]; a second launch adds the slices.
+// addresses per LayerNorm backward).  ONE launch: a 1024-thread workgroup owns 64 columns of one of the four arrays; its 16 lane
+// groups each add every 16th partial (independent loads, eight in flight per lane), the 16 group sums are added in order through LDS.
 constexpr int LN_RS = 16;
-__global__ __launch_bounds__(1024) void ln_colsum_reduce1_kernel(const float* __restrict__ partial, float* __restrict__ partial2, int nblocks, int D,
-                                                                   unsigned present) {
+__global__ __launch_bounds__(1024) void ln_colsum_reduce_kernel(const float* __restrict__ partial, int nblocks, int D, float* d0, float* d1,
+                                                                  float* d2, float* d3) {
     __shared__ float red[16][64];
-    const int which = blockIdx.y, z = blockIdx.z;
-    if (!((present >> which) & 1u)) return;
+    const int which = blockIdx.y;
+    float* dst = which == 0 ? d0 : which == 1 ? d1 : which == 2 ? d2 : d3;
+    if (!dst) return;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    const int chunk = (nblocks + LN_RS - 1) / LN_RS, b0 = z * chunk, b1 = min(nblocks, b0 + chunk);
     float s = 0.f;
-    if (c < D)
-        for (int b = b0 + g; b < b1; b += 16) s += partial[((size_t)b * 4 + which) * D + c];
+    if (c < D) {
+#pragma unroll 8
+        for (int b = g; b < nblocks; b += 16) s += partial[((size_t)b * 4 + which) * D + c];
+    }
     red[g][cl] = s;
     __syncthreads();
     if (g == 0 && c < D) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][cl];
-        partial2[((size_t)z * 4 + which) * D + c] = t;
+        dst[c] += t;
     }
-}
-__global__ __launch_bounds__(256) void ln_colsum_reduce2_kernel(const float* __restrict__ partial2, int D, float* d0, float* d1, float* d2, float* d3) {
-    const int which = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    float* dst = which == 0 ? d0 : which == 1 ? d1 : which == 2 ? d2 : d3;
-    if (!dst || c >= D) return;
-    float t = 0.f;
-#pragma unroll
-    for (int z = 0; z < LN_RS; ++z) t += partial2[((size_t)z * 4 + which) * D + c];
-    dst[c] += t;
 }
 
 int ln_bwd_grid(int rows) { const int g = (rows + WAVES * 8 - 1) / (WAVES * 8); return g < 2048 ? g : 2048; }
@@ -397,10 +390,7 @@ int ppf_layernorm_bwd_blocks(int rows) { return ln_bwd_grid(rows) + LN_RS; }
 int ppf_layernorm_bwd_reduce(const float* partial, int rows, int D, float* dw, float* db, float* dbias_next, float* dcolscale, hipStream_t stream) {
     PPF_CHECK_ARG(partial && rows > 0 && D > 0, PPF_ERR_ARG, "ppf_layernorm_bwd_reduce: bad arguments");
     const int nb = ln_bwd_grid(rows);
-    float* partial2 = const_cast<float*>(partial) + (size_t)nb * 4 * D;
-    const unsigned present = (dw ? 1u : 0u) | (db ? 2u : 0u) | (dbias_next ? 4u : 0u) | (dcolscale ? 8u : 0u);
-    hipLaunchKernelGGL(ln_colsum_reduce1_kernel, dim3((D + 63) / 64, 4, LN_RS), dim3(1024), 0, stream, partial, partial2, nb, D, present);
-    hipLaunchKernelGGL(ln_colsum_reduce2_kernel, dim3((D + 255) / 256, 4), dim3(256), 0, stream, partial2, D, dw, db, dbias_next, dcolscale);
+    hipLaunchKernelGGL(ln_colsum_reduce_kernel, dim3((D + 63) / 64, 4), dim3(1024), 0, stream, partial, nb, D, dw, db, dbias_next, dcolscale);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -1,5 +1,3 @@
 #!/bin/bash
-python -c "
-import torch
-print('priority range', torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream,'priority_range') else 'n/a')"
-timeout 1500 python scripts/gpu/ab_step.py 2 "base:" "mainprio:PPF_MAIN_PRIORITY=1"
+timeout 900 python -m pytest tests/test_gpu_norm_elementwise.py tests/test_gpu_e2e.py tests/test_gpu_cait.py -q 2>&1 | tail -2
+timeout 900 python scripts/gpu/ab_step.py 2 "base:"
