@@ -146,47 +146,75 @@ class WgradLane:
     optimizer consumes it), and the dgrad / LayerNorm / attention kernels of the chain rarely fill all 256 CUs, so the
     wgrads run concurrently with them.  Hazards: a wgrad reads tensors produced on the main stream (the lane waits for the
     main stream before each launch), temporaries may be freed while the lane still reads them (they are held until the next
-    join), and the in-place bf16 gradient buffer is overwritten by the next LayerNorm backward (before_overwrite).
-    Ordering goes through the library's pooled events (ppf_stream_wait_stream / _mark / _wait_mark): one C call per dependency;
-    the functions submitted here must not allocate torch memory (they run with torch's current stream unchanged and only the
+    join), and a buffer the main stream writes again while the lane may still read it must be registered with track() and
+    guarded with before_overwrite().
+    Ordering goes through the library's pooled events (ppf_stream_wait_stream / _mark / _wait_mark).  Every event record is a
+    packet in its queue (measured ~3 us of main-stream time each, profiles/r2_lane_events.txt), so they are kept few:
+    submit(defer=True) launches together with the NEXT submit under one main-stream event (the LayerNorm column-sum reduction and
+    the weight gradient that follows it), and only launches that read a tracked buffer are followed by a side-stream mark.
+    The functions submitted here must not allocate torch memory (they run with torch's current stream unchanged and only the
     library's launch stream redirected).  PPF_WGRAD_STREAM=0 runs everything on the main stream."""
 
     def __init__(self, device):
         self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
         self.stream = torch.cuda.Stream(device=device) if self.enabled else None
         self.raw = self.stream.cuda_stream if self.enabled else None
-        self.last_read = {}
+        self.last_read = {}         # data_ptr of a tracked buffer -> ticket of the last side-stream launch that reads it
+        self.tracked = set()
         self.held = []              # tensors the lane reads, kept alive (so their memory is not reused) until the next join()
+        self.pending = []           # deferred launches (fn, reads)
         self._disabled_tags = {k[len("PPF_LANE_"):] for k, v in os.environ.items() if k.startswith("PPF_LANE_") and v == "0"}
 
-    def submit(self, fn, reads, tag=None):
+    def track(self, t):
+        """t is a buffer the main stream will write again during this backward pass (see before_overwrite)."""
+        self.tracked.add(t.data_ptr())
+        return t
+
+    def submit(self, fn, reads, tag=None, defer=False):
         if not self.enabled or (tag is not None and tag in self._disabled_tags):
             fn()
+            return
+        self.pending.append((fn, reads))
+        self.held.extend(reads)
+        if not defer:
+            self.flush()
+
+    def flush(self):
+        if not self.pending:
             return
         L = _lib.lib()
         if L.ppf_stream_wait_stream(self.raw, _lib.stream_ptr()):
             raise RuntimeError(L.ppf_last_error().decode())
         _lib.push_stream(self.raw)
         try:
-            fn()
+            for fn, reads in self.pending:
+                fn()
+                ptrs = [t.data_ptr() for t in reads if t.data_ptr() in self.tracked]
+                if ptrs:
+                    ticket = L.ppf_stream_mark(self.raw)
+                    if ticket < 0:
+                        raise RuntimeError(L.ppf_last_error().decode())
+                    for q in ptrs:
+                        self.last_read[q] = ticket
         finally:
             _lib.pop_stream()
-        ticket = L.ppf_stream_mark(self.raw)
-        if ticket < 0:
-            raise RuntimeError(L.ppf_last_error().decode())
-        for t in reads:
-            self.held.append(t)
-            self.last_read[t.data_ptr()] = ticket
+            self.pending.clear()
 
     def before_overwrite(self, t):
+        """The main stream is about to write t: wait for the side stream's last launch that reads it."""
+        if t.data_ptr() not in self.tracked:
+            raise RuntimeError("WgradLane.before_overwrite: buffer was not registered with track()")
+        self.flush()
         ticket = self.last_read.pop(t.data_ptr(), None)
         if ticket is not None:
             _lib.call("ppf_stream_wait_mark", _lib.stream_ptr(), ticket)
 
     def join(self):
         if self.enabled:
+            self.flush()
             _lib.call("ppf_stream_wait_stream", _lib.stream_ptr(), self.raw)
         self.last_read.clear()
+        self.tracked.clear()
         self.held.clear()
 
 
@@ -226,14 +254,30 @@ def deit_backward(ppnet, store, saved, df):
     # (x_last is already the reserved rows when the last blocks ran compacted: then nothing is scattered here)
     alloc = ops.zeros if head["row_map"] is not None else (lambda shape, dtype, device: torch.empty(shape, dtype=dtype, device=device))
     dx = alloc((M, D), torch.float32, dev)
-    dyb = alloc((M, D), torch.bfloat16, dev)
+    dyb = lane.track(alloc((M, D), torch.bfloat16, dev))
     last = feats.blocks[-1]
     lnb(dnf, x_last.reshape(M, D), feats.norm.weight, head["meanf"], head["rstdf"], store.grad_view(feats.norm.weight),
                       store.grad_view(feats.norm.bias), dx_out=dx, row_map=head["row_map"], cast_out=dyb, rowscale=layers[-1]["s2"],
                       rows_per_group=N, dbias_next=store.grad_view(last.mlp.fc2.bias))
     gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
     if gs is not None:
+        lane.flush()
         gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
+    # The bf16 branch gradient alternates between two buffers: the LayerNorm backward that produces the next one does not have to
+    # wait for the side stream's weight-gradient GEMM that still reads the current one (the main stream would otherwise be tied to
+    # the progress of the side stream twice per block).  PPF_DYB_PINGPONG=0: one buffer, overwritten in place.
+    pingpong = os.environ.get("PPF_DYB_PINGPONG", "1") != "0"
+    dyb_alt = None
+
+    def next_dyb(cur, alt):
+        if not pingpong:
+            lane.before_overwrite(cur)
+            return cur, None
+        if alt is None or alt.shape != cur.shape:
+            alt = lane.track(torch.empty_like(cur))
+        lane.before_overwrite(alt)
+        return alt, cur
+
     for i in range(len(layers) - 1, -1, -1):
         L, blk = layers[i], feats.blocks[i]
         Nl = L["N"]                                       # tokens per sample in this block (1+k once compacted)
@@ -242,7 +286,7 @@ def deit_backward(ppnet, store, saved, df):
         dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
         _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
-        lane.before_overwrite(dyb)
+        dyb, dyb_alt = next_dyb(dyb, dyb_alt)
         lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
                           store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl,
                           dbias_next=store.grad_view(blk.attn.proj.bias))
@@ -255,7 +299,7 @@ def deit_backward(ppnet, store, saved, df):
         dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
             prev = feats.blocks[i - 1]
-            lane.before_overwrite(dyb)
+            dyb, dyb_alt = next_dyb(dyb, dyb_alt)
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
                               rows_per_group=Nl, dbias_next=store.grad_view(prev.mlp.fc2.bias))
@@ -263,11 +307,13 @@ def deit_backward(ppnet, store, saved, df):
                 # this block ran on the reserved rows: hand its input gradient back to the full token matrix (zeros elsewhere)
                 Mf = B * layers[i - 1]["N"]
                 dx = ops.scatter_rows(dx, L["rows"], Mf)
-                dyb = ops.scatter_rows(dyb, L["rows"], Mf)
+                dyb = lane.track(ops.scatter_rows(dyb, L["rows"], Mf))
+                dyb_alt = None
         else:
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
+            lane.flush()
             gs.chunk_ready(gs.block_chunk[i], also=(lane.stream,))
     # token assembly + patch embedding
     pe = feats.patch_embed
@@ -277,6 +323,7 @@ def deit_backward(ppnet, store, saved, df):
     dtok = ops.assemble_tokens_bwd(dx, store.grad_view(feats.pos_embed).reshape(Np + 1, D), store.grad_view(feats.cls_token).reshape(D), B, Np, D, 1)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
+        lane.flush()
         gs.chunk_ready(gs.head_chunk, also=(lane.stream,))
     lane.join()
 

@@ -249,7 +249,7 @@ def cait_backward(ppnet, store, saved, df):
     # ---- class-attention blocks (reverse)
     for j in range(len(ca) - 1, -1, -1):
         L, blk = ca[j], feats.blocks_token_only[j]
-        dyb = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
+        dyb = lane.track(torch.empty((B, D), dtype=torch.bfloat16, device=dev))
         lnb(None, None, None, None, None, None, None, dres_in=dcls, cast_out=dyb, colscale=blk.gamma_2,
                           dbias_next=gv(blk.mlp.fc2.bias), branch=L["raw2"], dcolscale=gv(blk.gamma_2))
         dn2 = _mlp_bwd(store, blk, L, dyb)
@@ -278,7 +278,7 @@ def cait_backward(ppnet, store, saved, df):
     lnb(None, None, None, None, None, None, None, dres_in=dcls, cast_out=scratch, dbias_next=gv(feats.cls_token).reshape(D))
     # ---- talking-heads blocks (reverse)
     dx = du3[:, 1:].contiguous().reshape(M, D)
-    dyb = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    dyb = lane.track(torch.empty((M, D), dtype=torch.bfloat16, device=dev))
     last = feats.blocks[-1]
     lnb(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
                       colscale=last.gamma_2, dbias_next=gv(last.mlp.fc2.bias), branch=sa[-1]["raw2"], dcolscale=gv(last.gamma_2))
@@ -304,12 +304,15 @@ def cait_backward(ppnet, store, saved, df):
         else:
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
+            lane.flush()
             gs.chunk_ready(gs.block_chunk[i], also=(lane.stream,))
     pe = feats.patch_embed
     dtok = ops.assemble_tokens_bwd(dx, gv(feats.pos_embed).reshape(N, D), None, B, N, D, 0)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
+        lane.flush()
         gs.chunk_ready(gs.head_chunk, also=(lane.stream,))
+        lane.flush()
         gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
     lane.join()
 

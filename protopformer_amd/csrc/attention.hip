@@ -492,10 +492,16 @@ template <int HD, int NT, int MINW, bool SPLITD>
 __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(const AttnParams p) {
     constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
     static_assert(NT <= NW, "one query / key tile per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + 4 * NT * 32 * 4];
-    unsigned char* tA = lds;                                   // phase A: K      phase B: Q
-    unsigned char* tB = lds + NT * 32 * 128;                   // phase A: V      phase B: dO
-    float* pol = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);
+    // K, V, Q and dO of the (batch, head) all live in LDS for the whole kernel (4 x 28 KiB at N <= 224; the register budget already
+    // limits this kernel to one workgroup per CU), so every global load is issued in ONE batch at the start: a single exposed memory
+    // round trip per workgroup instead of two.
+    constexpr int TILE = NT * 32 * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* tK = lds;
+    unsigned char* tV = lds + TILE;
+    unsigned char* tA = lds + 2 * TILE;                        // Q
+    unsigned char* tB = lds + 3 * TILE;                        // dO
+    float* pol = reinterpret_cast<float*>(lds + 4 * TILE);
     float* st_m = pol + NT * 32;
     float* st_z = st_m + NT * 32;
     float* st_d = st_z + NT * 32;
@@ -507,19 +513,16 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(con
     const int r0 = wave * 32;                      // this wave's query tile (phase A) and key tile (phase B)
     const bool active = wave < NT && r0 < N;
     const int row = r0 + (lane & 31), rc = min(row, N - 1);
-    bf16x8 qf[KS], dof[KS], ovf[KS];
+    bf16x8 ovf[KS];
     {
-        Stage<HD, NT * 32, NTHR> sk, sv;           // every global load of the prologue in flight before the first LDS write
+        Stage<HD, NT * 32, NTHR> sk, sv, sq, so;   // every global load of the kernel in flight before the first LDS write
         sk.template load<true>(base + p.D, p.ld, 0, N, tid);
         sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
-        const bf16_t* dorow = dobase + (size_t)rc * p.D;
+        sq.template load<false>(base, p.ld, 0, N, tid);
+        so.template load<false>(dobase, p.D, 0, N, tid);
         const bf16_t* orow = p.out + ((size_t)b * N + rc) * p.D + h * HD;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)rc * p.ld + ks * 16 + hh * 8);
-            dof[ks] = *reinterpret_cast<const bf16x8*>(dorow + ks * 16 + hh * 8);
-            ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
-        }
+        for (int ks = 0; ks < KS; ++ks) ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
         for (int i = tid; i < NT * 32; i += NTHR) {
             const size_t si = ((size_t)b * p.H + h) * N + i;
             pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
@@ -527,10 +530,17 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(con
             st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
             st_d[i] = 0.f;                            // rows of query tiles no wave owns stay finite
         }
-        sk.store(tA, tid);
-        sv.store(tB, tid);
+        sk.store(tK, tid);
+        sv.store(tV, tid);
+        sq.store(tA, tid);
+        so.store(tB, tid);
     }
     __syncthreads();
+    bf16x8 qf[KS], dof[KS];
+    if (active) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_rows(tA, r0, ks, lane); dof[ks] = frag_rows(tB, r0, ks, lane); }
+    }
     // ---------------------------------------------------------------- phase A: delta, dQ
     if (active) {
         const int qself = p.self_keep ? row : -1;
@@ -554,8 +564,8 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(con
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tA, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
-                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tB, t * 32, ks, lane), dof[ks], g, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tV, t * 32, ks, lane), dof[ks], g, 0, 0, 0);
             }
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
@@ -574,7 +584,7 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(con
                 const bf16x8 dsf = pack8(s, 8 * st);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tA, t * 32 + 16 * st, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, t * 32 + 16 * st, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
             }
         }
         if (row < N) {
@@ -590,20 +600,11 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(con
                 }
         }
     }
-    // this wave's K / V rows for phase B come out of the LDS image before it is overwritten; Q / dO are re-read (L2) meanwhile
+    // ---------------------------------------------------------------- phase B: dK, dV (delta of every query tile must be in LDS)
     bf16x8 kf[KS], vf[KS];
-    {
-        Stage<HD, NT * 32, NTHR> sq, so;
-        sq.template load<false>(base, p.ld, 0, N, tid);
-        so.template load<false>(dobase, p.D, 0, N, tid);
-        if (active) {
+    if (active) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag_rows(tA, r0, ks, lane); vf[ks] = frag_rows(tB, r0, ks, lane); }
-        }
-        __syncthreads();
-        // ---------------------------------------------------------------- phase B: dK, dV
-        sq.store(tA, tid);
-        so.store(tB, tid);
+        for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag_rows(tK, r0, ks, lane); vf[ks] = frag_rows(tV, r0, ks, lane); }
     }
     __syncthreads();
     if (!active) return;
@@ -753,10 +754,16 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
         using G = Geo<decltype(nt)::value>;
         dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
         if (fused) {            // one launch: both phases share the staged tiles (PPF_ATTN_BWD_FUSED=0: the two-kernel form)
-            constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value, W2 = G::NW == 8 ? 4 : 2;
-            if (fused == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<HDv, NTv, W2, false>), dim3(1, H, B), dim3(G::NTHR), 0, stream, p);
-            else if (fused == 3) hipLaunchKernelGGL((attn_bwd_fused_kernel<HDv, NTv, W2, true>), dim3(1, H, B), dim3(G::NTHR), 0, stream, p);
-            else hipLaunchKernelGGL((attn_bwd_fused_kernel<HDv, NTv, 2, false>), dim3(1, H, B), dim3(G::NTHR), 0, stream, p);
+            constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
+            constexpr int lds_bytes = 4 * NTv * 32 * 128 + 4 * NTv * 32 * 4;
+            auto kern = attn_bwd_fused_kernel<HDv, NTv, 2, false>;
+            static bool attr_set = false;                  // one flag per instantiation (the lambda is instantiated per (hd, nt))
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(1, H, B), dim3(G::NTHR), lds_bytes, stream, p);
             PPF_LAUNCH_CHECK();
             return 0;
         }
