@@ -350,35 +350,34 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
 typedef __attribute__((address_space(3))) void g4_lds_t;
 typedef const __attribute__((address_space(1))) void g4_gbl_t;
 
-template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams p) {
+template <int EPI, int MT, int OCC>
+__global__ __launch_bounds__(NTHREADS, OCC) void gemm128g_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using IO = TileIO<false, 128>;
+    constexpr int TBM = 64 * MT, NLA = 2 * MT;                 // A rows per workgroup, 32-row load instructions per K tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int wm = (wave & 1) * (32 * MT), wn = (wave >> 1) * 64;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (vid / tiles_n) * BM, n0 = (vid % tiles_n) * BN;
+    const int m0 = (vid / tiles_n) * TBM, n0 = (vid % tiles_n) * BN;
     unsigned char* tA = smem;
-    unsigned char* tB = smem + TILE_BYTES;
-    unsigned offA[4], offB[4];
+    unsigned char* tB = smem + TBM * BK * 2;
+    unsigned offA[NLA], offB[4];
     {
         const int rb = tid >> 3, ch = (tid & 7) ^ ((rb >> 1) & 7);       // rows rb + 32 i share the swizzle
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ra = min(m0 + rb + 32 * i, p.M - 1), rn = min(n0 + rb + 32 * i, p.N - 1);
-            offA[i] = ((unsigned)ra * (unsigned)p.lda + ch * 8) * 2u;
-            offB[i] = ((unsigned)rn * (unsigned)p.ldb + ch * 8) * 2u;
-        }
+        for (int i = 0; i < NLA; ++i) offA[i] = ((unsigned)min(m0 + rb + 32 * i, p.M - 1) * (unsigned)p.lda + ch * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offB[i] = ((unsigned)min(n0 + rb + 32 * i, p.N - 1) * (unsigned)p.ldb + ch * 8) * 2u;
     }
     const unsigned char* gA = reinterpret_cast<const unsigned char*>(p.A);
     const unsigned char* gB = reinterpret_cast<const unsigned char*>(p.B);
-    f32x16 acc[2][2];
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -388,23 +387,24 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams 
         const unsigned char* ka = gA + (size_t)kt * (BK * 2);
         const unsigned char* kb = gB + (size_t)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLA; ++i)
             __builtin_amdgcn_global_load_lds((g4_gbl_t*)(ka + offA[i]), (g4_lds_t*)(tA + i * 4096 + wave * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((g4_gbl_t*)(kb + offB[i]), (g4_lds_t*)(tB + i * 4096 + wave * 1024), 16, 0, 0);
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[MT], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = IO::frag(tA, wm + 32 * i, ks, lane);
+            for (int i = 0; i < MT; ++i) fa[i] = IO::frag(tA, wm + 32 * i, ks, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) fb[i] = IO::frag(tB, wn + 32 * i, ks, lane);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         }
     }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams 
     const int h = lane >> 5;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * STAGE_LD);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -426,21 +426,29 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm128g_kernel(const GemmParams 
     }
 }
 
-template <int EPI>
-int launch_g4(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm128g_kernel<EPI>;
-    constexpr int lds = (2 * TILE_BYTES) > STAGE_BYTES ? (2 * TILE_BYTES) : STAGE_BYTES;
+template <int EPI, int MT, int OCC>
+int launch_g4_mt(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm128g_kernel<EPI, MT, OCC>;
+    constexpr int TBM = 64 * MT;
+    constexpr int opnd = TBM * BK * 2 + TILE_BYTES;
+    constexpr int lds = opnd > STAGE_BYTES ? opnd : STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm128g): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), lds, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;
 }
+
+// MT = 4 (256x128 workgroup tiles, 128x64 per wave: 25 % fewer LDS fragment bytes per MFMA) was measured SLOWER at three and at two
+// workgroups per CU (qkv 60.6 -> 83.6 / 69.0 us, fc1+GELU 132 -> 155 / 146 us, train step -5.4 % / -1.9 %; profiles/r2_gemm_knockout.txt):
+// what these K = 384 GEMMs want is more independent workgroups per CU, not fewer LDS bytes.  Only MT = 2 is instantiated.
+template <int EPI>
+int launch_g4(const GemmParams& p, hipStream_t stream) { return launch_g4_mt<EPI, 2, 4>(p, stream); }
 
 bool g4_eligible(const GemmParams& p) {
     static const int mode = getenv("PPF_GEMM_G4") ? atoi(getenv("PPF_GEMM_G4")) : 1;
@@ -590,26 +598,6 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
-    // PPF_GEMM_PD_X=d: the register-pipelined 128x128 kernel with d K tiles in flight for the forward (NT) / dgrad (NN) GEMMs
-    static const int pd_x = getenv("PPF_GEMM_PD_X") ? atoi(getenv("PPF_GEMM_PD_X")) : 0;
-    if (pd_x == 2 || pd_x == 3) {
-#define PPF_PDX(TB_, EPI_) (pd_x == 3 ? launch_impl<false, TB_, EPI_, false, 2, 3>(p, 1, stream, 1) : launch_impl<false, TB_, EPI_, false, 2, 2>(p, 1, stream, 1))
-        if (!trans_a && !trans_b) {
-            switch (epi) {
-                case EPI_BF16: return PPF_PDX(false, EPI_BF16);
-                case EPI_GELU: return PPF_PDX(false, EPI_GELU);
-                case EPI_RESID: return PPF_PDX(false, EPI_RESID);
-                default: break;
-            }
-        } else if (!trans_a && trans_b) {
-            switch (epi) {
-                case EPI_BF16: return PPF_PDX(true, EPI_BF16);
-                case EPI_DGELU: return PPF_PDX(true, EPI_DGELU);
-                default: break;
-            }
-        }
-#undef PPF_PDX
-    }
     if (!trans_a && !trans_b) {
         if (nt256_eligible(p, epi)) return launch_nt256(p, epi, stream);
         if (g4_eligible(p)) {
