@@ -21,6 +21,7 @@
 namespace {
 
 constexpr float SOFTMAX_EPS = 1e-6f;     // deit:29 eps
+constexpr float LOG2E = 1.44269504088896340736f;
 
 struct AttnParams {
     const bf16_t* qkv;     // [B*N][ld] : q | k | v at column offsets 0, D, 2D (+ h*HD)
@@ -675,6 +676,221 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, one pass
+// Every (query tile, key tile) pair is visited ONCE: wave w owns key tile w (its K / V fragments stay in registers, dK / dV
+// accumulate in registers) and walks the query tiles in the rotated order t = (w + i) mod NT, so that in step i the NT waves work on
+// NT different query tiles.  The dQ contribution of a pair is added to that query tile's fp32 accumulator in LDS by plain
+// read-modify-write -- the rotation gives every wave exclusive ownership of its tile between two barriers, and the order in which
+// the key tiles reach a query tile is fixed (bit-identical from run to run, no atomics).  dS is needed in two layouts (keys in the
+// lanes for dK, queries in the lanes for dQ): it is written once, as bf16 [key][query], into a 4 KiB per-wave scratch tile and read
+// back transposed (ds_read_b64_tr_b16).  Per pair: 20 MFMA 32x32x16 (S, dP, dV, dK, dQ) and ONE softmax evaluation, against 28 and
+// two for the two-phase kernel above.  LDS: Q and dO images (2 x NT x 4 KiB), dQ accumulators (NT x 8 KiB), scratch, row statistics
+// = 147.5 KiB at NT = 7; K and V never enter LDS except for the one transposed copy of the wave's own K tile.
+template <int HD, int NT>
+struct OnePassLds {
+    static constexpr int TILE = NT * 32 * 128, DT = (HD + 31) / 32;
+    static constexpr int ACC = NT * DT * 4096 + Geo<NT>::NW * 4096;
+    static constexpr int MID = ACC > 3 * TILE ? ACC : 3 * TILE;
+    static constexpr int BYTES = 2 * TILE + MID + 5 * NT * 32 * 4;
+};
+template <int HD, int NT>
+__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_onepass_kernel(const AttnParams p) {
+    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
+    static_assert(NT <= NW, "one key tile per wave");
+    constexpr int TILE = NT * 32 * 128;
+    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
+    constexpr int DQT = DT * 4 * 64 * 4;                        // floats of one query tile's dQ accumulator: [dt][g][lane][4]
+    constexpr int MID = OnePassLds<HD, NT>::MID;               // dQ accumulators + scratch tiles; K, V and O images during the prologue
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* tQ = lds;
+    unsigned char* tO = lds + TILE;                            // dO
+    float* dqacc = reinterpret_cast<float*>(lds + 2 * TILE);
+    unsigned char* scr_all = lds + 2 * TILE + NT * DQT * 4;
+    float* pol = reinterpret_cast<float*>(lds + 2 * TILE + MID);
+    float* st_m = pol + NT * 32;
+    float* st_z = st_m + NT * 32;
+    float* st_d = st_z + NT * 32;
+    float* st_cz = st_d + NT * 32;
+    unsigned char* tK = lds + 2 * TILE;                        // prologue only (aliases dqacc / scratch)
+    unsigned char* tV = tK + TILE;
+    unsigned char* tOut = tV + TILE;                           // O (forward output), for delta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
+    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
+    const int r0 = wave * 32;                      // this wave's key tile (and the query tile whose delta / dQ rows it handles)
+    const bool active = wave < NT && r0 < N;
+    const int row = r0 + l31, rc = min(row, N - 1);
+    unsigned char* scr = scr_all + wave * 4096;
+    const float sc2 = p.scale * LOG2E;
+    {
+        Stage<HD, NT * 32, NTHR> sq, so, sk, sv, sx;   // every global load of the kernel in flight before the first LDS write
+        sq.template load<false>(base, p.ld, 0, N, tid);
+        so.template load<false>(p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, N, tid);
+        sk.template load<true>(base + p.D, p.ld, 0, N, tid);          // clamped: padded keys repeat the last valid row (finite, keep = 0)
+        sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
+        sx.template load<false>(p.out + (size_t)b * N * p.D + h * HD, p.D, 0, N, tid);
+        for (int i = tid; i < NT * 32; i += NTHR) {
+            const size_t si = ((size_t)b * p.H + h) * N + i;
+            const float zi = i < N ? p.zinv[si] : 0.f;   // zero => padded queries contribute nothing
+            pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+            st_m[i] = i < N ? p.rowmax[si] * LOG2E : 0.f;
+            st_z[i] = zi;
+            st_cz[i] = p.eps_c * zi;                     // the eps / N term of the policy softmax, per query
+            st_d[i] = 0.f;
+        }
+        sq.store(tQ, tid);
+        so.store(tO, tid);
+        sk.store(tK, tid);
+        sv.store(tV, tid);
+        sx.store(tOut, tid);
+    }
+    __syncthreads();
+    // own key tile: K and V rows (second operands of S and dP) and K^T (first operand of the dQ product: output index d, contraction
+    // over the 32 keys); delta = rowsum(dO * O) of the own query tile
+    bf16x8 kf[KS], vf[KS], ktr[2][DT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag_rows(tK, r0, ks, lane); vf[ks] = frag_rows(tV, r0, ks, lane); }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ktr[st][dt] = frag_tr(tK, r0 + 16 * st, dt * 32, lane);
+    if (active) {
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 dof = frag_rows(tO, r0, ks, lane), ovf = frag_rows(tOut, r0, ks, lane);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)dof[e] * (float)ovf[e];
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (hh == 0) st_d[row] = row < N ? dl : 0.f;
+    }
+    __syncthreads();                               // K / V / O images are dead from here
+    {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < NT * DQT / 4; i += NTHR) reinterpret_cast<float4*>(dqacc)[i] = z4;
+    }
+    __syncthreads();
+
+    const float keep_key = row < N ? pol[rc] : 0.f;
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+#pragma unroll 1
+    for (int i = 0; i < NT; ++i) {
+        if (active) {
+            int t = wave + i;
+            if (t >= NT) t -= NT;
+            f32x16 s, g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tQ, t * 32, ks, lane), kf[ks], s, 0, 0, 0);   // [q][key]
+                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tO, t * 32, ks, lane), vf[ks], g, 0, 0, 0);   // dO.V^T
+            }
+            // softmax + dS on the packed fp32 pipe (two queries per instruction); exp2 with log2(e) folded into the scale and the saved
+            // row maximum.  Only the diagonal pair (t == own tile) contains "a masked query still attends to itself" positions.
+            const bool diag = t == wave && p.self_keep;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int qq0 = t * 32 + 8 * gg + 4 * hh;
+                const float4 m4 = *reinterpret_cast<const float4*>(st_m + qq0), z4 = *reinterpret_cast<const float4*>(st_z + qq0),
+                             d4 = *reinterpret_cast<const float4*>(st_d + qq0), c4 = *reinterpret_cast<const float4*>(st_cz + qq0);
+                const ppf_float2 mm[2] = {{m4.x, m4.y}, {m4.z, m4.w}}, zz[2] = {{z4.x, z4.y}, {z4.z, z4.w}}, dd[2] = {{d4.x, d4.y}, {d4.z, d4.w}},
+                                 cz[2] = {{c4.x, c4.y}, {c4.z, c4.w}};
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int r = 4 * gg + 2 * jp;
+                    ppf_float2 kk = {keep_key, keep_key};
+                    if (diag) {
+                        if (qq0 + 2 * jp == row) kk.x = 1.0f;
+                        if (qq0 + 2 * jp + 1 == row) kk.y = 1.0f;
+                    }
+                    const ppf_float2 sv = {s[r], s[r + 1]}, gv = {g[r], g[r + 1]};
+                    const ppf_float2 x = sv * sc2 - mm[jp];
+                    ppf_float2 e; e.x = __builtin_amdgcn_exp2f(x.x); e.y = __builtin_amdgcn_exp2f(x.y);
+                    const ppf_float2 pt = e * zz[jp] * kk;
+                    const ppf_float2 ds = pt * (gv - dd[jp]), po = pt + cz[jp];
+                    s[r] = ds.x; s[r + 1] = ds.y;                                  // dS[q][key]
+                    g[r] = po.x; g[r + 1] = po.y;                                  // out[q][key]
+                }
+                // dS as bf16 [key][query] for the transposed read below: this lane's key row, queries 8 gg + 4 hh .. + 3
+                *reinterpret_cast<uint2*>(scr + row_off(l31, gg) + 8 * hh) =
+                    make_uint2(pack_bf16x2(s[4 * gg], s[4 * gg + 1]), pack_bf16x2(s[4 * gg + 2], s[4 * gg + 3]));
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 dsf = pack8(s, 8 * st), pf = pack8(g, 8 * st);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, t * 32 + 16 * st, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tO, t * 32 + 16 * st, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                }
+            }
+            // dQ^T[d][q] of this pair: K^T (registers) x dS^T (scratch, keys in the contraction slots, queries in the lanes)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float* qa = dqacc + t * DQT + lane * 4;
+            f32x16 dq[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 v = *reinterpret_cast<const float4*>(qa + (dt * 4 + gq) * 256);
+                    dq[dt][4 * gq] = v.x; dq[dt][4 * gq + 1] = v.y; dq[dt][4 * gq + 2] = v.z; dq[dt][4 * gq + 3] = v.w;
+                }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 dst = frag_tr(scr, 16 * st, 0, lane);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[st][dt], dst, dq[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<float4*>(qa + (dt * 4 + gq) * 256) = make_float4(dq[dt][4 * gq], dq[dt][4 * gq + 1], dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+        }
+        __syncthreads();                           // the next step's owner of each query tile sees this step's sums
+    }
+    // results as bf16 row images (dK over the Q image, dV over the dO image, dQ over the scratch tiles), then 16-byte row-contiguous
+    // stores by the whole workgroup: the accumulator layout (a lane = a row, 8-byte pieces) would store 32 scattered pieces per instruction
+    unsigned char* tDQ = scr_all;
+    if (active) {
+        const float* qa = dqacc + wave * DQT + lane * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c16 = dt * 4 + g;
+                if (c16 * 8 < HD) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(qa + (dt * 4 + g) * 256);
+                    *reinterpret_cast<uint2*>(tDQ + row_off(row, c16) + 8 * hh) =
+                        make_uint2(pack_bf16x2(q4.x * p.scale, q4.y * p.scale), pack_bf16x2(q4.z * p.scale, q4.w * p.scale));
+                    *reinterpret_cast<uint2*>(tQ + row_off(row, c16) + 8 * hh) =
+                        make_uint2(pack_bf16x2(dk[dt][4 * g] * p.scale, dk[dt][4 * g + 1] * p.scale), pack_bf16x2(dk[dt][4 * g + 2] * p.scale, dk[dt][4 * g + 3] * p.scale));
+                    *reinterpret_cast<uint2*>(tO + row_off(row, c16) + 8 * hh) =
+                        make_uint2(pack_bf16x2(dv[dt][4 * g], dv[dt][4 * g + 1]), pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]));
+                }
+            }
+    }
+    __syncthreads();
+    {
+        constexpr int CH = HD / 8;
+        bf16_t* dst = p.dqkv + (size_t)b * N * p.ld + h * HD;
+        for (int i = tid; i < N * CH; i += NTHR) {
+            const int r = i / CH, cc = i - r * CH;
+            bf16_t* o = dst + (size_t)r * p.ld + cc * 8;
+            *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(tDQ + row_off(r, cc));
+            *reinterpret_cast<uint4*>(o + p.D) = *reinterpret_cast<const uint4*>(tQ + row_off(r, cc));
+            *reinterpret_cast<uint4*>(o + 2 * p.D) = *reinterpret_cast<const uint4*>(tO + row_off(r, cc));
+        }
+    }
+}
+
 template <typename F>
 int dispatch(int hd, int N, const char* who, F&& f) {
     const int nt = (N + 31) / 32;
@@ -749,15 +965,28 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
-    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 1;
+    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 4;
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
-        if (fused) {            // one launch: both phases share the staged tiles (PPF_ATTN_BWD_FUSED=0: the two-kernel form)
-            constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
+        constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
+        if (fused == 4) {       // one pass over the (query tile, key tile) pairs
+            constexpr int lds_bytes = OnePassLds<HDv, NTv>::BYTES;
+            auto kern = attn_bwd_onepass_kernel<HDv, NTv>;
+            static bool attr_set = false;                  // one flag per instantiation (the lambda is instantiated per (hd, nt))
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(1, H, B), dim3(G::NTHR), lds_bytes, stream, p);
+            PPF_LAUNCH_CHECK();
+            return 0;
+        }
+        if (fused) {            // one launch, two phases over the staged tiles (PPF_ATTN_BWD_FUSED=1; 0: the two-kernel form)
             constexpr int lds_bytes = 4 * NTv * 32 * 128 + 4 * NTv * 32 * 4;
             auto kern = attn_bwd_fused_kernel<HDv, NTv, 2, false>;
-            static bool attr_set = false;                  // one flag per instantiation (the lambda is instantiated per (hd, nt))
+            static bool attr_set = false;
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
                 if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
