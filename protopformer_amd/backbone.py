@@ -204,8 +204,10 @@ class WgradLane:
         """The main stream is about to write t: wait for the side stream's last launch that reads it."""
         if t.data_ptr() not in self.tracked:
             raise RuntimeError("WgradLane.before_overwrite: buffer was not registered with track()")
-        self.flush()
-        ticket = self.last_read.pop(t.data_ptr(), None)
+        q = t.data_ptr()
+        if any(r.data_ptr() == q for _, reads in self.pending for r in reads):
+            self.flush()
+        ticket = self.last_read.pop(q, None)
         if ticket is not None:
             _lib.call("ppf_stream_wait_mark", _lib.stream_ptr(), ticket)
 
