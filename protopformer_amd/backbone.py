@@ -157,8 +157,10 @@ class WgradLane:
 
     def __init__(self, device):
         self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
-        self.stream = torch.cuda.Stream(device=device) if self.enabled else None
-        self.raw = self.stream.cuda_stream if self.enabled else None
+        nl = int(os.environ.get("PPF_LANES", "1"))
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(nl)] if self.enabled else []
+        self.raws = [st.cuda_stream for st in self.streams]
+        self._rr = 0
         self.last_read = {}         # data_ptr of a tracked buffer -> ticket of the last side-stream launch that reads it
         self.tracked = set()
         self.held = []              # tensors the lane reads, kept alive (so their memory is not reused) until the next join()
@@ -183,15 +185,17 @@ class WgradLane:
         if not self.pending:
             return
         L = _lib.lib()
-        if L.ppf_stream_wait_stream(self.raw, _lib.stream_ptr()):
+        raw = self.raws[self._rr]
+        self._rr = (self._rr + 1) % len(self.raws)
+        if L.ppf_stream_wait_stream(raw, _lib.stream_ptr()):
             raise RuntimeError(L.ppf_last_error().decode())
-        _lib.push_stream(self.raw)
+        _lib.push_stream(raw)
         try:
             for fn, reads in self.pending:
                 fn()
                 ptrs = [t.data_ptr() for t in reads if t.data_ptr() in self.tracked]
                 if ptrs:
-                    ticket = L.ppf_stream_mark(self.raw)
+                    ticket = L.ppf_stream_mark(raw)
                     if ticket < 0:
                         raise RuntimeError(L.ppf_last_error().decode())
                     for q in ptrs:
@@ -214,7 +218,8 @@ class WgradLane:
     def join(self):
         if self.enabled:
             self.flush()
-            _lib.call("ppf_stream_wait_stream", _lib.stream_ptr(), self.raw)
+            for raw in self.raws:
+                _lib.call("ppf_stream_wait_stream", _lib.stream_ptr(), raw)
         self.last_read.clear()
         self.tracked.clear()
         self.held.clear()
@@ -264,7 +269,7 @@ def deit_backward(ppnet, store, saved, df):
     gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
     if gs is not None:
         lane.flush()
-        gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
+        gs.chunk_ready(gs.tail_chunk, also=lane.streams)
     # The bf16 branch gradient alternates between two buffers: the LayerNorm backward that produces the next one does not have to
     # wait for the side stream's weight-gradient GEMM that still reads the current one (the main stream would otherwise be tied to
     # the progress of the side stream twice per block).  PPF_DYB_PINGPONG=0: one buffer, overwritten in place.
@@ -316,7 +321,7 @@ def deit_backward(ppnet, store, saved, df):
                               store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.flush()
-            gs.chunk_ready(gs.block_chunk[i], also=(lane.stream,))
+            gs.chunk_ready(gs.block_chunk[i], also=lane.streams)
     # token assembly + patch embedding
     pe = feats.patch_embed
     Np = pe.num_patches
@@ -326,7 +331,7 @@ def deit_backward(ppnet, store, saved, df):
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
         lane.flush()
-        gs.chunk_ready(gs.head_chunk, also=(lane.stream,))
+        gs.chunk_ready(gs.head_chunk, also=lane.streams)
     lane.join()
 
 

@@ -305,15 +305,15 @@ def cait_backward(ppnet, store, saved, df):
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.flush()
-            gs.chunk_ready(gs.block_chunk[i], also=(lane.stream,))
+            gs.chunk_ready(gs.block_chunk[i], also=lane.streams)
     pe = feats.patch_embed
     dtok = ops.assemble_tokens_bwd(dx, gv(feats.pos_embed).reshape(N, D), None, B, N, D, 0)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
         lane.flush()
-        gs.chunk_ready(gs.head_chunk, also=(lane.stream,))
+        gs.chunk_ready(gs.head_chunk, also=lane.streams)
         lane.flush()
-        gs.chunk_ready(gs.tail_chunk, also=(lane.stream,))
+        gs.chunk_ready(gs.tail_chunk, also=lane.streams)
     lane.join()
 
 
