@@ -15,9 +15,13 @@
 //   proto_bwd_protos : one workgroup per prototype, waves own samples, scan the token axis
 #include "ppf_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
+#ifndef PPF_PROTO_OCC
+#define PPF_PROTO_OCC 3
+#endif
 constexpr int PB = 128;           // prototypes per workgroup (4 waves x 32)
 constexpr int BKF = 32;           // contraction chunk (floats)
 constexpr int LDP = BKF + 1;      // padded LDS pitch: conflict-free ds_read_b32 for the MFMA operands
@@ -41,11 +45,229 @@ __device__ __forceinline__ float activation(float d, int kind, float eps) {
     return kind == 0 ? __logf((d + 1.0f) / (d + eps)) : -d;
 }
 
+// Everything after the contraction: distances (protopformer.py:213-216 association order), activations, max-pool + arg-max over the
+// tokens, the (B,P) outputs and the full (B,P,T) maps.  acc[t][r] = <token row, prototype of this lane>; lx2 holds |x|^2 per row.
 template <int TT, bool POOL>
-__global__ __launch_bounds__(256) void proto_fwd_kernel(const ProtoFwdParams p) {
+__device__ __forceinline__ void proto_fwd_epilogue(const ProtoFwdParams& p, f32x16 (&acc)[TT], float* lds, const float* lx2, float p2, int p0,
+                                                   int grp, int nrows, int lane, int wave, int hh) {
+    constexpr int ROWS = TT * 32;
+    const int pidx = p0 + wave * 32 + (lane & 31);
+    float best = -INFINITY;
+    int besti = 0;
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float d = fmaxf(lx2[row] + (-2.0f * acc[t][r] + p2), 0.0f);      // protopformer.py:213-216 association order
+            acc[t][r] = d;
+            if (POOL && row < p.T) {
+                const float a = activation(d, p.act_kind, p.eps);
+                if (a > best) { best = a; besti = row; }
+            }
+        }
+    if (POOL) {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(besti, 32, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        if (hh == 0 && pidx < p.P) {
+            p.act_max[(size_t)grp * p.P + pidx] = best;
+            p.argmax[(size_t)grp * p.P + pidx] = besti;
+        }
+    } else {
+        // one token per sample: rows are samples, no pooling
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int smp = grp * ROWS + row;
+                if (row < nrows && pidx < p.P) {
+                    p.act_max[(size_t)smp * p.P + pidx] = activation(acc[t][r], p.act_kind, p.eps);
+                    if (p.dist_full) p.dist_full[(size_t)smp * p.P + pidx] = acc[t][r];
+                    if (p.act_full) p.act_full[(size_t)smp * p.P + pidx] = activation(acc[t][r], p.act_kind, p.eps);
+                }
+            }
+        return;
+    }
+    // full maps (B,P,T): transpose the wave's [token][prototype] tile through LDS, 16 prototypes at a time.  The 16 rows of T floats
+    // are ONE contiguous range of the map (prototypes are consecutive), written as 16-byte pieces when the range is so aligned.
+    float* xp = lds + wave * 16 * (ROWS + 1);
+    const int pw = p0 + wave * 32;                       // first prototype of this wave
+    for (int pass = 0; pass < 2; ++pass) {
+        float* dst = pass == 0 ? p.dist_full : p.act_full;
+        if (!dst) continue;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (((lane & 31) >> 4) == half) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        xp[(lane & 15) * (ROWS + 1) + row] = pass == 0 ? acc[t][r] : activation(acc[t][r], p.act_kind, p.eps);
+                    }
+            }
+            __syncthreads();
+            const int pf = pw + 16 * half;               // first prototype of this half
+            const int np = min(16, p.P - pf);            // prototypes of this half that exist
+            if (np <= 0) continue;
+            float* obase = dst + ((size_t)grp * p.P + pf) * p.T;
+            const int total = np * p.T;
+            if ((((size_t)grp * p.P + pf) * p.T) % 4 == 0) {
+                for (int f = lane * 4; f < total; f += 256) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ff = min(f + e, total - 1), pp = ff / p.T, tt = ff - pp * p.T;
+                        v[e] = xp[pp * (ROWS + 1) + tt];
+                    }
+                    if (f + 4 <= total) *reinterpret_cast<float4*>(obase + f) = make_float4(v[0], v[1], v[2], v[3]);
+                    else for (int e = 0; f + e < total; ++e) obase[f + e] = v[e];
+                }
+            } else {
+                for (int f = lane; f < total; f += 64) { const int pp = f / p.T, tt = f - pp * p.T; obase[f] = xp[pp * (ROWS + 1) + tt]; }
+            }
+        }
+    }
+}
+
+// ---- split-bf16 contraction ------------------------------------------------------------------------------------------------
+// fp32 x = a + b + c with a = bf16(x), b = bf16(x - a), c = bf16(x - a - b): three 8-bit pieces hold the 24-bit significand exactly.
+// <x, p> = sum over the six piece products with (piece index of x) + (piece index of p) <= 2 -- each product of two bf16 values is
+// exact in fp32, the dropped terms are below 3 * 2^-24 |x||p|, i.e. at the rounding level of an fp32 multiply -- on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 32 cycles per 16 contraction values instead of 8 x 64 for the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), which bounds proto_fwd_kernel below (measured 450 of 561 us).  |x|^2 and |p|^2 stay plain fp32 sums.
+struct Split3 { uint32_t a, b, c; };               // two values per register: the pieces of (lo, hi)
+__device__ __forceinline__ Split3 split3(float lo, float hi) {
+    Split3 r;
+    r.a = pack_bf16x2(lo, hi);
+    const float l1 = lo - __uint_as_float(r.a << 16), h1 = hi - __uint_as_float(r.a & 0xffff0000u);
+    r.b = pack_bf16x2(l1, h1);
+    const float l2 = l1 - __uint_as_float(r.b << 16), h2 = h1 - __uint_as_float(r.b & 0xffff0000u);
+    r.c = pack_bf16x2(l2, h2);
+    return r;
+}
+__device__ __forceinline__ int p6_off(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }   // 128-byte rows, chunk swizzle
+
+template <int TT, bool POOL>
+__global__ __launch_bounds__(256, 3) void proto_fwd6_kernel(const ProtoFwdParams p) {
+    constexpr int ROWS = TT * 32, BK6 = 64;
+    constexpr int PLANE = ROWS * 128;                              // bytes: [ROWS][64 bf16], one piece
+    constexpr int STAGE = 3 * PLANE / 4;                           // floats
+    constexpr int XPOSE = 4 * 16 * (ROWS + 1);
+    __shared__ __attribute__((aligned(16))) float lds[(STAGE > XPOSE ? STAGE : XPOSE) + ROWS];
+    unsigned char* planes = reinterpret_cast<unsigned char*>(lds);
+    float* lx2 = lds + (STAGE > XPOSE ? STAGE : XPOSE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, l31 = lane & 31;
+    const int p0 = blockIdx.x * PB, grp = blockIdx.y;
+    const int nrows = POOL ? p.T : min(ROWS, p.B - grp * ROWS);
+
+    f32x16 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // token rows: global -> registers (next chunk in flight while this one is multiplied) -> three bf16 piece images in LDS
+    constexpr int NLD = ROWS * (BK6 / 4) / 256;                    // float4 per thread and chunk (ROWS is a multiple of 32)
+    static_assert(ROWS * (BK6 / 4) % 256 == 0, "whole float4 per thread");
+    float4 stg[NLD];
+    float x2p[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) x2p[j] = 0.f;
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256, row = i >> 4, c4 = i & 15;
+            const int rr = min(row, nrows - 1);                    // rows past the end repeat the last one (never written out)
+            const float* src = POOL ? p.tok + (size_t)grp * p.stride_b + (size_t)(p.t0 + rr) * p.Dp
+                                    : p.tok + (size_t)(grp * ROWS + rr) * p.stride_b + (size_t)p.t0 * p.Dp;
+            const int kk = min(k0 + c4 * 4, p.Dp - 4);
+            float4 v = *reinterpret_cast<const float4*>(src + kk);
+            if (k0 + c4 * 4 >= p.Dp) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            stg[j] = v;
+        }
+    };
+    auto sstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256, row = i >> 4, c4 = i & 15;
+            const float4 v = stg[j];
+            x2p[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            const Split3 s0 = split3(v.x, v.y), s1 = split3(v.z, v.w);
+            const int off = p6_off(row, c4 >> 1) + 8 * (c4 & 1);
+            *reinterpret_cast<uint2*>(planes + off) = make_uint2(s0.a, s1.a);
+            *reinterpret_cast<uint2*>(planes + PLANE + off) = make_uint2(s0.b, s1.b);
+            *reinterpret_cast<uint2*>(planes + 2 * PLANE + off) = make_uint2(s0.c, s1.c);
+        }
+    };
+    // prototype row of this lane: straight from global (L2) in fragment order, 8 contraction values per 16-step, split in registers
+    const int pidx_c = min(p0 + wave * 32 + l31, p.P - 1);
+    const float* prow = p.protos + (size_t)pidx_c * p.Dp + 8 * hh;
+    float p2p = 0.f;
+    auto pload = [&](int k, float4& u0, float4& u1) __attribute__((always_inline)) {
+        const int kk = min(k, p.Dp - 16);                          // Dp % 16 == 0 is checked on the host
+        u0 = *reinterpret_cast<const float4*>(prow + kk);
+        u1 = *reinterpret_cast<const float4*>(prow + kk + 4);
+    };
+    float4 q0, q1;
+    gload(0);
+    pload(0, q0, q1);
+    for (int k0 = 0; k0 < p.Dp; k0 += BK6) {
+        __syncthreads();                                             // everyone finished reading the previous chunk
+        sstore();
+        __syncthreads();
+        if (k0 + BK6 < p.Dp) gload(k0 + BK6);
+#pragma unroll
+        for (int ks = 0; ks < BK6 / 16; ++ks) {
+            if (k0 + ks * 16 < p.Dp) {
+                const float4 u0 = q0, u1 = q1;
+                pload(k0 + ks * 16 + 16, q0, q1);                    // next 16-step (clamped re-read at the end)
+                p2p += u0.x * u0.x + u0.y * u0.y + u0.z * u0.z + u0.w * u0.w + u1.x * u1.x + u1.y * u1.y + u1.z * u1.z + u1.w * u1.w;
+                const Split3 b0 = split3(u0.x, u0.y), b1 = split3(u0.z, u0.w), b2 = split3(u1.x, u1.y), b3 = split3(u1.z, u1.w);
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                const bf16x8 pa = __builtin_bit_cast(bf16x8, (u32x4){b0.a, b1.a, b2.a, b3.a});
+                const bf16x8 pb = __builtin_bit_cast(bf16x8, (u32x4){b0.b, b1.b, b2.b, b3.b});
+                const bf16x8 pc = __builtin_bit_cast(bf16x8, (u32x4){b0.c, b1.c, b2.c, b3.c});
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const int off = p6_off(t * 32 + l31, ks * 2 + hh);
+                    const bf16x8 xa = *reinterpret_cast<const bf16x8*>(planes + off);
+                    const bf16x8 xb = *reinterpret_cast<const bf16x8*>(planes + PLANE + off);
+                    const bf16x8 xc = *reinterpret_cast<const bf16x8*>(planes + 2 * PLANE + off);
+                    // smallest terms first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xc, pa, acc[t], 0, 0, 0);     // D[i = token][j = prototype]
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, pc, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, pb, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, pa, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, pb, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, pa, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float p2 = p2p + __shfl_xor(p2p, 32, 64);
+    __syncthreads();
+    // |x|^2 per row: the 16 threads that staged a row's float4 pieces are 16 consecutive lanes
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        float v = x2p[j];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        const int i = tid + j * 256;
+        if ((i & 15) == 0) lx2[i >> 4] = v;
+    }
+    __syncthreads();
+    proto_fwd_epilogue<TT, POOL>(p, acc, lds, lx2, p2, p0, grp, nrows, lane, wave, hh);
+}
+
+template <int TT, bool POOL>
+__global__ __launch_bounds__(256, PPF_PROTO_OCC) void proto_fwd_kernel(const ProtoFwdParams p) {
     constexpr int ROWS = TT * 32;
     constexpr int STAGE = (ROWS + PB) * LDP;                       // floats
-    constexpr int XPOSE = 4 * 32 * (ROWS + 1);                     // per-wave [32 p][ROWS+1] transpose tiles
+    constexpr int XPOSE = 4 * 16 * (ROWS + 1);                     // per-wave [16 p][ROWS+1] transpose tiles (two halves per map): with
+                                                                   // the operand stage <= 30 KiB this leaves room for five workgroups per CU
     __shared__ float lds[(STAGE > XPOSE ? STAGE : XPOSE) + ROWS];
     float* ltok = lds;
     float* lpro = lds + ROWS * LDP;
@@ -126,66 +348,7 @@ __global__ __launch_bounds__(256) void proto_fwd_kernel(const ProtoFwdParams p) 
         }
     }
     __syncthreads();
-    const int pidx = p0 + wave * 32 + (lane & 31);
-    float best = -INFINITY;
-    int besti = 0;
-#pragma unroll
-    for (int t = 0; t < TT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float d = fmaxf(lx2[row] + (-2.0f * acc[t][r] + p2), 0.0f);      // protopformer.py:213-216 association order
-            acc[t][r] = d;
-            if (POOL && row < p.T) {
-                const float a = activation(d, p.act_kind, p.eps);
-                if (a > best) { best = a; besti = row; }
-            }
-        }
-    if (POOL) {
-        const float ob = __shfl_xor(best, 32, 64);
-        const int oi = __shfl_xor(besti, 32, 64);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-        if (hh == 0 && pidx < p.P) {
-            p.act_max[(size_t)grp * p.P + pidx] = best;
-            p.argmax[(size_t)grp * p.P + pidx] = besti;
-        }
-    } else {
-        // one token per sample: rows are samples, no pooling
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int smp = grp * ROWS + row;
-                if (row < nrows && pidx < p.P) {
-                    p.act_max[(size_t)smp * p.P + pidx] = activation(acc[t][r], p.act_kind, p.eps);
-                    if (p.dist_full) p.dist_full[(size_t)smp * p.P + pidx] = acc[t][r];
-                    if (p.act_full) p.act_full[(size_t)smp * p.P + pidx] = activation(acc[t][r], p.act_kind, p.eps);
-                }
-            }
-        return;
-    }
-    // full maps (B,P,T): transpose the wave's [token][prototype] tile through LDS -> token-contiguous stores
-    float* xp = lds + wave * 32 * (ROWS + 1);
-    for (int pass = 0; pass < 2; ++pass) {
-        float* dst = pass == 0 ? p.dist_full : p.act_full;
-        if (!dst) continue;
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                xp[(lane & 31) * (ROWS + 1) + row] = pass == 0 ? acc[t][r] : activation(acc[t][r], p.act_kind, p.eps);
-            }
-        __syncthreads();
-        for (int pp = 0; pp < 32; ++pp) {
-            const int pi = p0 + wave * 32 + pp;
-            if (pi >= p.P) break;
-            float* orow = dst + ((size_t)grp * p.P + pi) * p.T;
-            for (int t = lane; t < p.T; t += 64) orow[t] = xp[pp * (ROWS + 1) + t];
-        }
-    }
+    proto_fwd_epilogue<TT, POOL>(p, acc, lds, lx2, p2, p0, grp, nrows, lane, wave, hh);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -445,15 +608,28 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
     p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
     p.act_max = act_max; p.argmax = argmax; p.dist_full = dist_full; p.act_full = act_full;
     const int gx = (P + PB - 1) / PB;
+    // default: the split-bf16 contraction; PPF_PROTO_FP32=1 (or Dp not a multiple of 16): the fp32-MFMA kernel
+    static const int fp32_mfma = getenv("PPF_PROTO_FP32") ? atoi(getenv("PPF_PROTO_FP32")) : 0;
+    const bool x6 = !fp32_mfma && Dp % 16 == 0;
     if (T == 1) {
-        hipLaunchKernelGGL((proto_fwd_kernel<2, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
+        if (x6) hipLaunchKernelGGL((proto_fwd6_kernel<2, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((proto_fwd_kernel<2, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
     } else {
         const int tt = (T + 31) / 32;
-        switch (tt) {
-            case 1: hipLaunchKernelGGL((proto_fwd_kernel<1, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
-            case 2: hipLaunchKernelGGL((proto_fwd_kernel<2, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
-            case 3: hipLaunchKernelGGL((proto_fwd_kernel<3, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((proto_fwd_kernel<4, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+        if (x6) {
+            switch (tt) {
+                case 1: hipLaunchKernelGGL((proto_fwd6_kernel<1, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                case 2: hipLaunchKernelGGL((proto_fwd6_kernel<2, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                case 3: hipLaunchKernelGGL((proto_fwd6_kernel<3, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                default: hipLaunchKernelGGL((proto_fwd6_kernel<4, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+            }
+        } else {
+            switch (tt) {
+                case 1: hipLaunchKernelGGL((proto_fwd_kernel<1, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                case 2: hipLaunchKernelGGL((proto_fwd_kernel<2, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                case 3: hipLaunchKernelGGL((proto_fwd_kernel<3, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                default: hipLaunchKernelGGL((proto_fwd_kernel<4, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+            }
         }
     }
     PPF_LAUNCH_CHECK();
