@@ -144,6 +144,12 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
                   float eps, const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok,
                   int64_t dstride_b, float* dprotos, void* zeroed_workspace, size_t workspace_bytes, ppf_stream_t stream);
 /* (workspace: B*T*ceil(P/32)*4 bytes, zero-filled by the caller: bitmap of the non-zero dL/dd entries) */
+/* T == 1 (global branch, protopformer.py:295,311 and its autograd): dense form of the same backward -- two fp32 products instead of the
+ * gather.  g [B][P] = upstream gradient of the activations, dist [B][P]; dtok rows are overwritten (when non-null), dprotos accumulated. */
+size_t ppf_proto_bwd_single_workspace(int B, int P, int Dp);
+int ppf_proto_bwd_single(const float* tok, int64_t stride_b, int t0, const float* protos, int B, int P, int Dp, int act_kind, float eps,
+                         const float* dist, const float* g, float* dtok, int64_t dstride_b, float* dprotos, void* workspace,
+                         size_t workspace_bytes, ppf_stream_t stream);
 
 /* ---- losses and the frozen class-connection head ------------------------------------------------------------------
  * PPC loss (protopformer.py:249-288): loss[0] = cov term, loss[1] = mean term; gcov/gmean [B][ppc][T] analytic grads. */

@@ -30,6 +30,7 @@ SIGS = {
     "ppf_rollout_threshold": "p" "iiii" "p" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",
+    "ppf_proto_bwd_single": "plip" "iiii" "f" "ppp" "l" "p" "pz" "s",
     "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
     "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",
     "ppf_cross_entropy": "ppppp" "ii" "s",
@@ -82,6 +83,8 @@ def lib():
         _lib.ppf_abi_version.restype = ctypes.c_int
         _lib.ppf_gemm_workspace_bytes.restype = ctypes.c_size_t
         _lib.ppf_gemm_workspace_bytes.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_proto_bwd_single_workspace.restype = ctypes.c_size_t
+        _lib.ppf_proto_bwd_single_workspace.argtypes = [ctypes.c_int] * 3
         _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int
         _lib.ppf_layernorm_bwd_blocks.argtypes = [ctypes.c_int]
         _lib.ppf_sigmoid_bwd_blocks.restype = ctypes.c_int

@@ -593,6 +593,56 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdPa
     }
 }
 
+// ---- T == 1 (the global / cls branch): every (sample, prototype) pair carries a gradient, so the gather form degenerates into two
+// dense fp32 products  dtok[b] = 2 (sum_p G[b,p]) tok[b] - 2 G protos,   dprotos[p] += 2 (sum_b G[b,p]) protos[p] - 2 G^T tok
+// with G[b,p] = g[b,p] * dact/dd(dist[b,p]).
+__global__ __launch_bounds__(256) void proto_single_gd_rows_kernel(const float* __restrict__ dist, const float* __restrict__ g, int P, int act_kind,
+                                                                    float eps, float* __restrict__ G, float* __restrict__ rowsum) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int pi = threadIdx.x; pi < P; pi += 256) {
+        const size_t o = (size_t)b * P + pi;
+        const float v = g[o] * dact_dd(dist[o], act_kind, eps);
+        G[o] = v;
+        s += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rowsum[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// G and its column sums: a workgroup owns 64 prototypes; its four waves take every fourth sample (coalesced 256-byte rows), their
+// partial sums are added in a fixed order
+__global__ __launch_bounds__(256) void proto_single_gd_cols_kernel(const float* __restrict__ dist, const float* __restrict__ g, int B, int P, int act_kind,
+                                                                    float eps, float* __restrict__ G, float* __restrict__ colsum) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pi = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (pi < P) {
+#pragma unroll 4
+        for (int b = wave; b < B; b += 4) {
+            const size_t o = (size_t)b * P + pi;
+            const float v = g[o] * dact_dd(dist[o], act_kind, eps);
+            G[o] = v;
+            s += v;
+        }
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && pi < P) colsum[pi] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+// out[r][:] += 2 * scale[r] * x[r][:]   (rows of Dp floats, independent row strides)
+__global__ __launch_bounds__(256) void proto_single_fixup_kernel(float* __restrict__ out, int64_t ostride, const float* __restrict__ x, int64_t xstride,
+                                                                  const float* __restrict__ scale, int R, int Dp) {
+    const int64_t n = (int64_t)R * Dp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / Dp), d = (int)(i - (int64_t)r * Dp);
+        out[r * ostride + d] += 2.0f * scale[r] * x[r * xstride + d];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -676,6 +726,52 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
     else if (nj <= 6) run(std::integral_constant<int, 6>());
     else run(std::integral_constant<int, 8>());
     PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int ldc,
+              float alpha, float beta, float* workspace, int64_t workspace_floats, hipStream_t stream);       // head.hip
+
+// Backward of ppf_proto_fwd for T == 1 as two dense products (see the kernels above).  g = upstream gradient of the activations [B][P]
+// (act_max == act_full when T == 1), dist [B][P].  dtok rows (tok layout) are overwritten when dtok != null; dprotos [P][Dp] is
+// accumulated (+=) when dprotos != null.  workspace: ppf_proto_bwd_single_workspace(B, P, Dp) bytes.
+size_t ppf_proto_bwd_single_workspace(int B, int P, int Dp) {
+    const size_t m = (size_t)(B > P ? B : P);
+    return ((size_t)B * P + m + 16 * m * (size_t)Dp) * sizeof(float);
+}
+int ppf_proto_bwd_single(const float* tok, int64_t stride_b, int t0, const float* protos, int B, int P, int Dp, int act_kind, float eps,
+                         const float* dist, const float* g, float* dtok, int64_t dstride_b, float* dprotos, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && Dp > 0, PPF_ERR_SHAPE, "ppf_proto_bwd_single: bad shape B=%d P=%d Dp=%d", B, P, Dp);
+    PPF_CHECK_ARG(tok && protos && dist && g && workspace && workspace_bytes >= ppf_proto_bwd_single_workspace(B, P, Dp), PPF_ERR_ARG,
+                  "ppf_proto_bwd_single: null pointer or workspace below ppf_proto_bwd_single_workspace() = %zu bytes", ppf_proto_bwd_single_workspace(B, P, Dp));
+    float* G = (float*)workspace;
+    float* sums = G + (size_t)B * P;
+    float* gemm_ws = sums + (B > P ? B : P);
+    const float* tok0 = tok + (size_t)t0 * Dp;
+    if (dtok) {
+        float* out = dtok + (size_t)t0 * Dp;
+        hipLaunchKernelGGL(proto_single_gd_rows_kernel, dim3(B), dim3(256), 0, stream, dist, g, P, act_kind, eps, G, sums);
+        PPF_LAUNCH_CHECK();
+        // out[b][d] = -2 sum_p G[b][p] protos[p][d]
+        int rc = ppf_sgemm(G, protos, out, B, Dp, P, P, 1, 1, Dp, (int)dstride_b, -2.0f, 0.0f, gemm_ws, (int64_t)16 * B * Dp, stream);
+        if (rc) return rc;
+        const int64_t n = (int64_t)B * Dp;
+        hipLaunchKernelGGL(proto_single_fixup_kernel, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream, out, dstride_b,
+                           tok0, stride_b, sums, B, Dp);
+        PPF_LAUNCH_CHECK();
+    }
+    if (dprotos) {
+        hipLaunchKernelGGL(proto_single_gd_cols_kernel, dim3((P + 63) / 64), dim3(256), 0, stream, dist, g, B, P, act_kind, eps, G, sums);
+        PPF_LAUNCH_CHECK();
+        // dprotos[p][d] += -2 sum_b G[b][p] tok[b][d]
+        int rc = ppf_sgemm(G, tok0, dprotos, P, Dp, B, 1, P, 1, stride_b, Dp, -2.0f, 1.0f, gemm_ws, (int64_t)16 * P * Dp, stream);
+        if (rc) return rc;
+        const int64_t n = (int64_t)P * Dp;
+        hipLaunchKernelGGL(proto_single_fixup_kernel, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream, dprotos, (int64_t)Dp,
+                           protos, (int64_t)Dp, sums, P, Dp);
+        PPF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -192,6 +192,12 @@ def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_
 def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4):
     B, Ttot, Dp = tokens.shape
     P = protos.shape[0]
+    if T == 1 and (g_full is None) != (g_max is None) and os.environ.get("PPF_PROTO_BWD_DENSE", "1") != "0":
+        # one token per sample: every (sample, prototype) pair carries a gradient -> two dense fp32 products instead of the gather
+        ws = _workspace(tokens.device, _lib.lib().ppf_proto_bwd_single_workspace(B, P, Dp))
+        _lib.call("ppf_proto_bwd_single", tokens, Ttot * Dp, t0, protos, B, P, Dp, act_kind, float(eps), dist, g_max if g_max is not None else g_full,
+                  dtok, Ttot * Dp, dprotos, ws, ws.numel())
+        return
     bitmap = zeros((B, T, (P + 31) // 32), torch.int32, tokens.device) if dtok is not None else None
     _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_full, g_max, argmax, dtok,
               Ttot * Dp, dprotos, bitmap, bitmap.numel() * 4 if bitmap is not None else 0)

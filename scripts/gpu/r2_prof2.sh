@@ -6,5 +6,6 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof
 cd $GRAFT_REPO_ROOT
 cut -c1-400 gpurun_out/prof_r2/bench.json
 python3 scripts/rocpd_timeline.py gpurun_out/prof_r2/r2_results.db > gpurun_out/r2_timeline_last.txt 2>&1
+python3 scripts/rocpd_window.py gpurun_out/prof_r2/r2_results.db > gpurun_out/r2_window.txt 2>&1
 rm -rf gpurun_out/prof_r2
 cat gpurun_out/r2_timeline_last.txt

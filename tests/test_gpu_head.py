@@ -173,3 +173,25 @@ def test_cross_entropy_and_frozen_head():
     dact = torch.empty(B, P, device="cuda")
     ops.sgemm(dl, w.cuda(), dact, B, P, C, C, 1, 1, P, alpha=0.5)            # dA = dlogits @ W
     assert_close(dact, 0.5 * lr.grad @ w, rtol=1e-4, atol=1e-6, what="frozen head dgrad")
+
+
+@pytest.mark.parametrize("B,Dp,P,kind", [(130, 64, 50, 0), (256, 384, 2000, 0), (7, 192, 333, 1)])
+def test_proto_bwd_single_token_dense_form(B, Dp, P, kind):
+    """T == 1 (global branch): the dense two-product backward (ppf_proto_bwd_single) against autograd of the oracle, with dtok and
+    dprotos requested in separate calls (as the train step does: main stream / side stream) and dprotos accumulated."""
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(B + P)
+    tokens = torch.rand(B, 3, Dp, generator=g)
+    protos = torch.rand(P, Dp, generator=g)
+    xt = tokens.clone().requires_grad_(True); pr = protos.clone().requires_grad_(True)
+    mx, d_ref, a_ref = O.proto_activations(xt[:, 1:2], pr, "log" if kind == 0 else "linear")
+    gmax = torch.randn(B, P, generator=g)
+    (mx * gmax).sum().backward()
+    act_max, _, dist, _ = ops.proto_fwd(tokens.cuda(), 1, 1, protos.cuda(), act_kind=kind)
+    dtok = torch.zeros(B, 3, Dp, device="cuda")
+    dpro = torch.full((P, Dp), 0.25, device="cuda")
+    ops.proto_bwd(tokens.cuda(), 1, 1, protos.cuda(), dist, None, gmax.cuda(), None, dtok, None, act_kind=kind)
+    ops.proto_bwd(tokens.cuda(), 1, 1, protos.cuda(), dist, None, gmax.cuda(), None, None, dpro, act_kind=kind)
+    assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens (dense form)")
+    assert float(dtok[:, 0].abs().max()) == 0.0 and float(dtok[:, 2].abs().max()) == 0.0        # only the token row is written
+    assert_close(dpro - 0.25, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes (dense form, accumulated)")
