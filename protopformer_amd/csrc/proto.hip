@@ -384,32 +384,52 @@ __device__ __forceinline__ float grad_d(const ProtoBwdParams& p, int b, int pi, 
 //          wherever dL/dd != 0 (order-independent atomic OR)
 //  gather: one wavefront per token (b,t) walks its bitmap row in ascending prototype order and accumulates
 //          2 G (x - p) in exact fp32 -- ~35 non-zeros per token, latency hidden by ~20k independent waves.
+// Candidate bitmap for proto_bwd_tokens: bit (b, t, p) is set where the upstream gradient of the activation map is non-zero or t is
+// the arg-max token of (b, p).  A superset of the non-zero dL/dd entries is enough (the consumer multiplies by the exact coefficient,
+// zero included), so neither the distances nor exact cancellations are looked at: the scan reads g_full once, 16 bytes per lane.
+// One workgroup per (sample, 32 prototypes): their rows are one contiguous range of 32 * T floats; word (b, t, p / 32) of the bitmap.
 __global__ __launch_bounds__(256) void proto_bwd_mark_kernel(const ProtoBwdParams p, uint32_t* __restrict__ bm, int W) {
-    const size_t total = (size_t)p.B * p.P * p.T;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int t = (int)(e % p.T);
-        const size_t bp = e / p.T;
-        float g = p.g_full ? p.g_full[e] : 0.f;
-        if (p.g_max) {
-            const int am = p.argmax ? p.argmax[bp] : 0;
-            if (t == am) g += p.g_max[bp];
+    const int w = blockIdx.x, b = blockIdx.y, T = p.T;
+    const int np = min(32, p.P - 32 * w);
+    const size_t base = ((size_t)b * p.P + 32 * w) * T;
+    const int total = np * T;
+    const float invT = 1.0f / (float)T;
+    if (p.g_full) {
+        const float* src = p.g_full + base;
+        if ((base & 3) == 0) {
+            for (int f = threadIdx.x * 4; f < total; f += 1024) {
+                float v[4];
+                if (f + 4 <= total) { const float4 q = *reinterpret_cast<const float4*>(src + f); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+                else { for (int e = 0; e < 4; ++e) v[e] = f + e < total ? src[f + e] : 0.f; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] != 0.f) {
+                        int pl = (int)(((float)(f + e) + 0.5f) * invT);                  // exact for f < 2^20
+                        int t = f + e - pl * T;
+                        if (t < 0) { --pl; t += T; } else if (t >= T) { ++pl; t -= T; }
+                        atomicOr(&bm[((size_t)b * T + t) * W + w], 1u << pl);
+                    }
+            }
+        } else {
+            for (int f = threadIdx.x; f < total; f += 256)
+                if (src[f] != 0.f) { const int pl = f / T, t = f - pl * T; atomicOr(&bm[((size_t)b * T + t) * W + w], 1u << pl); }
         }
-        if (g != 0.f && dact_dd(p.dist_full[e], p.act_kind, p.eps) != 0.f) {
-            const int b = (int)(bp / p.P), pi = (int)(bp % p.P);
-            atomicOr(&bm[((size_t)b * p.T + t) * W + (pi >> 5)], 1u << (pi & 31));
+    }
+    if (p.g_max && threadIdx.x < np) {
+        const size_t bp = (size_t)b * p.P + 32 * w + threadIdx.x;
+        if (p.g_max[bp] != 0.f) {
+            const int am = p.argmax ? p.argmax[bp] : 0;
+            atomicOr(&bm[((size_t)b * T + am) * W + w], 1u << threadIdx.x);
         }
     }
 }
-
-// One 8-wave workgroup per token (b,t): wave w owns an eighth of the prototype axis.  The arg-max routing piles most
-// prototypes of a sample onto a few tokens, so a token's non-zeros are (1) compacted per wave into an ascending LDS list,
-// (2) their dL/dd evaluated 64 at a time across the lanes (all gathers in flight together), (3) applied as
-// 2 G (x - p) row updates four prototype rows per step, and (4) the eight partial rows reduced through LDS in fixed order.
-template <int NJ>
-__global__ __launch_bounds__(512) void proto_bwd_tokens_kernel(const ProtoBwdParams p, const uint32_t* __restrict__ bm, int W) {
-    constexpr int NW = 8;
-    __shared__ unsigned short plist[NW][8 * 32 * 4];       // up to 32 words per wave (P <= 8192)
-    __shared__ float part[NW][NJ * 64];
+// NW waves per (sample, token) row, each owning ceil(W / NW) <= 64 words of the row's bitmap.  NW = 1 (P <= 2048): a row is one
+// independent wavefront -- no barrier, no cross-wave reduction, eight of them per SIMD to hide the dependent loads (bitmap -> list ->
+// coefficients -> prototype rows); the 8-wave form ran 20 rounds of ~9 us workgroups (185 us for 20 736 rows).
+template <int NJ, int NW>
+__global__ __launch_bounds__(64 * NW) void proto_bwd_tokens_kernel(const ProtoBwdParams p, const uint32_t* __restrict__ bm, int W) {
+    __shared__ unsigned short plist[NW][64 * 32];          // up to 64 words per wave
+    __shared__ float part[NW > 1 ? NW : 1][NW > 1 ? NJ * 64 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = blockIdx.x;                            // (b, t)
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(512) void proto_bwd_tokens_kernel(const ProtoBwdPar
     float x[NJ], acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; x[j] = d < p.Dp ? xrow[d] : 0.f; acc[j] = 0.f; }
-    const int wpw = (W + NW - 1) / NW;                     // words per wave (<= 32)
+    const int wpw = (W + NW - 1) / NW;                     // words per wave (<= 64)
     const int w_begin = wave * wpw, w_end = min(W, w_begin + wpw);
     // (1) ascending list of this wave's prototypes with a non-zero gradient for this token
     const uint32_t mine = (w_begin + lane < w_end) ? bm[(size_t)row * W + w_begin + lane] : 0u;
@@ -461,11 +481,16 @@ __global__ __launch_bounds__(512) void proto_bwd_tokens_kernel(const ProtoBwdPar
                 for (int j = 0; j < NJ; ++j) acc[j] += gs[u] * (x[j] - v[u][j]);
         }
     }
+    float* drow = p.dtok + (size_t)b * p.dstride_b + (size_t)(p.t0 + t) * p.Dp;
+    if constexpr (NW == 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < p.Dp) drow[d] = acc[j]; }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) part[wave][j * 64 + lane] = acc[j];
     __syncthreads();
-    float* drow = p.dtok + (size_t)b * p.dstride_b + (size_t)(p.t0 + t) * p.Dp;
-    for (int i = threadIdx.x; i < NJ * 64; i += 512) {
+    for (int i = threadIdx.x; i < NJ * 64; i += 64 * NW) {
         const int d = (i & 63) + 64 * (i >> 6);
         if (d < p.Dp) {
             float sacc = 0.f;
@@ -704,10 +729,9 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
     auto run = [&](auto njc) {
         constexpr int NJ = decltype(njc)::value;
         if (dtok) {
-            const size_t total = (size_t)B * P * T;
-            const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-            hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(grid), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
-            hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
+            hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(W, B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
+            if (W <= 64) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 1>), dim3(B * T), dim3(64), 0, stream, p, (const uint32_t*)workspace, W);
+            else hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 8>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
         }
         if (dprotos) {
             constexpr int lds = PB_NW * PB_CHUNK * 6 + PB_NW * NJ * 64 * 4 + (PB_NW + 1) * 4;
