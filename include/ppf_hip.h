@@ -164,6 +164,8 @@ int ppf_cross_entropy(const float* logits, const void* label_i64, float* per_sam
 int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk,
               int ldc, float alpha, float beta, float* workspace, int64_t workspace_floats, ppf_stream_t stream);
 int ppf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, ppf_stream_t stream);
+/* out = a x + b y + c z: loss = CE + ppc_cov_coe * cov + ppc_mean_coe * mean in one launch (tools/engine_proto.py:61-64) */
+int ppf_axpbypcz(const float* x, const float* y, const float* z, float* out, float a, float b, float c, int64_t n, ppf_stream_t stream);
 
 /* ---- streaming kernels -------------------------------------------------------------------------------------------- */
 int ppf_cast_f32_bf16(const float* in, void* out, int64_t n, ppf_stream_t stream);

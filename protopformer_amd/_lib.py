@@ -36,6 +36,7 @@ SIGS = {
     "ppf_cross_entropy": "ppppp" "ii" "s",
     "ppf_sgemm": "ppp" "iii" "llll" "i" "ff" "pl" "s",
     "ppf_axpby": "ppp" "ff" "l" "s",
+    "ppf_axpbypcz": "pppp" "fff" "l" "s",
     "ppf_topk_sorted": "piiips",
     "ppf_gemm_bf16_batched": "ppp" "iiiiii" "iii" "f" "ii" "llllll" "i" "s",
     "ppf_th_scores": "pppp" "iiiii" "s",

@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restri
     *c = alpha * s + (beta != 0.f ? beta * *c : 0.f);
 }
 
+__global__ __launch_bounds__(256) void axpbypcz_kernel(const float* x, const float* y, const float* z, float* out, float a, float b, float c, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a * x[i] + b * y[i] + c * z[i];
+}
 __global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, float a, float b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a * x[i] + b * y[i];
 }
@@ -250,6 +253,15 @@ int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, in
         hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, workspace, C, M, N, ldc, S, alpha, beta);
         PPF_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// out = a x + b y + c z  (the train loop's loss = CE + 0.1 cov + 0.5 mean in one launch, engine_proto.py:61-64)
+int ppf_axpbypcz(const float* x, const float* y, const float* z, float* out, float a, float b, float c, int64_t n, hipStream_t stream) {
+    PPF_CHECK_ARG(n > 0 && x && y && z && out, PPF_ERR_ARG, "ppf_axpbypcz: bad arguments");
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(axpbypcz_kernel, dim3((int)(g > 1024 ? 1024 : g)), dim3(256), 0, stream, x, y, z, out, a, b, c, n);
+    PPF_LAUNCH_CHECK();
     return 0;
 }
 

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, ops
-from .protopformer import CrossEntropyLoss
+from .protopformer import CrossEntropyLoss, WeightedLossFn
 
 DEFAULT_LRS = {"features": 1e-4, "add_on_layers": 3e-3, "prototype_vectors": 3e-3}       # main.py:64-66
 
@@ -356,13 +356,13 @@ def _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_
     if use_ppc_loss:
         cov, mean = model.get_PPC_loss(auxi[2], auxi[3], auxi[4], targets)
         if epoch >= 20:                                           # engine_proto.py:61-64
-            loss = loss + ppc_cov_coe * cov + ppc_mean_coe * mean
+            loss = WeightedLossFn.apply(loss, cov, mean, ppc_cov_coe, ppc_mean_coe)
     if check_finite and not math.isfinite(loss.item()):           # engine_proto.py:66-70 (host sync: opt-in)
         print("Loss is {}, stopping training".format(loss.item()))
         sys.exit(1)
     optimizer.zero_grad()
     model._grad_sync = grad_sync
-    loss.backward()
+    loss.backward(gradient=ops.const_scalar(loss.device, 1.0))    # cached seed: no ones_like fill, and the loss Fns skip their scaling
     model._grad_sync = None
     if grad_sync is not None:
         optimizer.grad_scale = grad_sync.finish()

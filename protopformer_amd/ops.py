@@ -237,6 +237,29 @@ def sgemm(a, b, out, M, N, K, sam, sak, sbn, sbk, alpha=1.0, beta=0.0):
     return out
 
 
+def axpbypcz(x, y, z, a, b, c):
+    out = torch.empty_like(x)
+    _lib.call("ppf_axpbypcz", x, y, z, out, float(a), float(b), float(c), x.numel())
+    return out
+
+
+_CONST = {}
+
+
+def const_scalar(device, value):
+    """A cached one-element fp32 device tensor (never written): seed / fixed coefficients of the loss backward without a fill launch."""
+    key = (device, float(value))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((), float(value), dtype=torch.float32, device=device)
+    return t
+
+
+def is_const_one(t):
+    c = _CONST.get((t.device, 1.0))
+    return c is not None and t.data_ptr() == c.data_ptr()
+
+
 def axpby(x, y, a, b, out=None):
     if out is None:
         out = torch.empty_like(x)

@@ -83,7 +83,9 @@ class ProtoLayerFn(torch.autograd.Function):
         store = ppnet.flat_store()
         store.attach_all_grads()
         B, T1, Dp = f.shape
-        df = ops.zeros(f.shape, f.dtype, f.device)
+        # every token row is written when both branches carry a gradient (the local rows 1.., the cls row 0): no zero fill then
+        full = (g_l is not None or g_full is not None) and g_g is not None
+        df = torch.empty(f.shape, dtype=f.dtype, device=f.device) if full else ops.zeros(f.shape, f.dtype, f.device)
         lane = wgrad_lane(store)      # prototype gradients feed only the optimizer: side stream, under the backbone backward
         torch.autograd.Variable._execution_engine.queue_callback(lane.join)     # ... joined when this backward pass ends
         if g_l is not None or g_full is not None:
@@ -161,7 +163,26 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, up):
         (dlogits,) = ctx.saved_tensors
+        if ops.is_const_one(up):                                                    # seeded by the train loop's cached one: nothing to scale
+            return dlogits, None
         return ops.scale_by_scalar(dlogits, up.float().contiguous()), None          # chain rule with the upstream (device) scalar
+
+
+class WeightedLossFn(torch.autograd.Function):
+    """loss = ce + c_cov * cov + c_mean * mean (tools/engine_proto.py:61-64) as one launch; the backward hands out cached constants when
+    it is seeded with the cached one (ops.const_scalar), so the loss arithmetic costs no further launches."""
+
+    @staticmethod
+    def forward(ctx, ce, cov, mean, c_cov, c_mean):
+        ctx.c = (float(c_cov), float(c_mean))
+        return ops.axpbypcz(ce.reshape(1), cov.reshape(1), mean.reshape(1), 1.0, c_cov, c_mean).reshape(())
+
+    @staticmethod
+    def backward(ctx, up):
+        c_cov, c_mean = ctx.c
+        if ops.is_const_one(up):
+            return up, ops.const_scalar(up.device, c_cov), ops.const_scalar(up.device, c_mean), None, None
+        return up, up * c_cov, up * c_mean, None, None
 
 
 class CrossEntropyLoss(nn.Module):
