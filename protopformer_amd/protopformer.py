@@ -331,7 +331,7 @@ class PPNet(nn.Module):
         f, cls_attn, idx, act_full, dist, logits, lg, ll = self._branches(x, want_dist=False)
         self._ppc_cache = (cls_attn, idx)
         total_proto_act = act_full.reshape(B, self.num_prototypes, s, s)
-        attn_loss = ops.zeros((1,), torch.float32, logits.device)
+        attn_loss = ops.const_scalar(logits.device, 0.0).reshape(1)      # protopformer.py:333 (a constant zero: cached, never written)
         return logits, (None, attn_loss, total_proto_act, cls_attn, self.num_patches)
 
     def push_forward(self, x):
