@@ -483,199 +483,6 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dkv_kernel(const At
 }
 
 
-// ------------------------------------------------------------------------------- backward: dQ, dK, dV in ONE launch
-// One workgroup per (batch, head), two phases over the same LDS image:
-//   phase A (as attn_bwd_dq): K / V staged, each wave owns a 32-query tile -> delta (kept in LDS, never in HBM) and dQ;
-//   phase B (as attn_bwd_dkv): Q / dO staged into the SAME LDS space, each wave owns a 32-key tile -> dK, dV.
-// Against the two-kernel form this reads K, V, Q, dO from HBM once instead of twice (the second touch of each is an L2 hit a
-// few microseconds after the first), drops the delta round trip and one launch: 470 -> ~310 MB per layer at (256, 6, 197, 64).
-template <int HD, int NT, int MINW, bool SPLITD>
-__global__ __launch_bounds__(Geo<NT>::NTHR, MINW) void attn_bwd_fused_kernel(const AttnParams p) {
-    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
-    static_assert(NT <= NW, "one query / key tile per wave");
-    // K, V, Q and dO of the (batch, head) all live in LDS for the whole kernel (4 x 28 KiB at N <= 224; the register budget already
-    // limits this kernel to one workgroup per CU), so every global load is issued in ONE batch at the start: a single exposed memory
-    // round trip per workgroup instead of two.
-    constexpr int TILE = NT * 32 * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* tK = lds;
-    unsigned char* tV = lds + TILE;
-    unsigned char* tA = lds + 2 * TILE;                        // Q
-    unsigned char* tB = lds + 3 * TILE;                        // dO
-    float* pol = reinterpret_cast<float*>(lds + 4 * TILE);
-    float* st_m = pol + NT * 32;
-    float* st_z = st_m + NT * 32;
-    float* st_d = st_z + NT * 32;
-    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
-    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    const bf16_t* dobase = p.dout + (size_t)b * N * p.D + h * HD;
-    const int r0 = wave * 32;                      // this wave's query tile (phase A) and key tile (phase B)
-    const bool active = wave < NT && r0 < N;
-    const int row = r0 + (lane & 31), rc = min(row, N - 1);
-    bf16x8 ovf[KS];
-    {
-        Stage<HD, NT * 32, NTHR> sk, sv, sq, so;   // every global load of the kernel in flight before the first LDS write
-        sk.template load<true>(base + p.D, p.ld, 0, N, tid);
-        sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
-        sq.template load<false>(base, p.ld, 0, N, tid);
-        so.template load<false>(dobase, p.D, 0, N, tid);
-        const bf16_t* orow = p.out + ((size_t)b * N + rc) * p.D + h * HD;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
-        for (int i = tid; i < NT * 32; i += NTHR) {
-            const size_t si = ((size_t)b * p.H + h) * N + i;
-            pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
-            st_m[i] = i < N ? p.rowmax[si] : 0.f;
-            st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
-            st_d[i] = 0.f;                            // rows of query tiles no wave owns stay finite
-        }
-        sk.store(tK, tid);
-        sv.store(tV, tid);
-        sq.store(tA, tid);
-        so.store(tB, tid);
-    }
-    __syncthreads();
-    bf16x8 qf[KS], dof[KS];
-    if (active) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { qf[ks] = frag_rows(tA, r0, ks, lane); dof[ks] = frag_rows(tB, r0, ks, lane); }
-    }
-    // ---------------------------------------------------------------- phase A: delta, dQ
-    if (active) {
-        const int qself = p.self_keep ? row : -1;
-        float dl = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ovf[ks][e];
-        dl += __shfl_xor(dl, 32, 64);
-        const float mx = st_m[rc], zi = row < N ? st_z[rc] : 0.f;
-        if (hh == 0) st_d[row] = row < N ? dl : 0.f;
-        f32x16 dq[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll 1
-        for (int t = 0; t < NT; ++t) {
-            f32x16 s, g;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
-                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tV, t * 32, ks, lane), dof[ks], g, 0, 0, 0);
-            }
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                const int key0 = t * 32 + 8 * gg + 4 * hh;
-                const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
-                const float keep[4] = {kp.x, kp.y, kp.z, kp.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float k = (key0 + i == qself) ? 1.0f : keep[i];
-                    const float pt = __expf(s[4 * gg + i] * p.scale - mx) * k * zi;   // padded keys: keep = 0
-                    s[4 * gg + i] = pt * (g[4 * gg + i] - dl);           // dS (before the scale factor)
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const bf16x8 dsf = pack8(s, 8 * st);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, t * 32 + 16 * st, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
-            }
-        }
-        if (row < N) {
-            bf16_t* orow = p.dqkv + ((size_t)b * N + row) * p.ld + h * HD;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = dt * 32 + 8 * g + 4 * hh;
-                    if (d < HD)
-                        *reinterpret_cast<uint2*>(orow + d) = make_uint2(pack_bf16x2(dq[dt][4 * g] * p.scale, dq[dt][4 * g + 1] * p.scale),
-                                                                         pack_bf16x2(dq[dt][4 * g + 2] * p.scale, dq[dt][4 * g + 3] * p.scale));
-                }
-        }
-    }
-    // ---------------------------------------------------------------- phase B: dK, dV (delta of every query tile must be in LDS)
-    bf16x8 kf[KS], vf[KS];
-    if (active) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { kf[ks] = frag_rows(tK, r0, ks, lane); vf[ks] = frag_rows(tV, r0, ks, lane); }
-    }
-    __syncthreads();
-    if (!active) return;
-    const int key = row;
-    const float keep_key = key < N ? pol[rc] : 0.f;
-    const int kself = p.self_keep ? key : -1;
-    const float c = p.eps_c;
-    // SPLITD: one 32-wide slice of the head dimension per pass over the query tiles (scores recomputed per slice): half the
-    // accumulator registers, so that two workgroups fit a CU
-    constexpr int DPASS = SPLITD ? DT : 1, DW = SPLITD ? 1 : DT;
-#pragma unroll 1
-    for (int dp = 0; dp < DPASS; ++dp) {
-        f32x16 dk[DW], dv[DW];
-#pragma unroll
-        for (int dt = 0; dt < DW; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-#pragma unroll 1
-        for (int t = 0; t < NT; ++t) {
-            f32x16 s, g;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tA, t * 32, ks, lane), kf[ks], s, 0, 0, 0);   // [q][key]
-                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tB, t * 32, ks, lane), vf[ks], g, 0, 0, 0);   // dO.V^T
-            }
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                const int qq0 = t * 32 + 8 * gg + 4 * hh;
-                const float4 m4 = *reinterpret_cast<const float4*>(st_m + qq0), z4 = *reinterpret_cast<const float4*>(st_z + qq0),
-                             d4 = *reinterpret_cast<const float4*>(st_d + qq0);
-                const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float k = (qq0 + i == kself) ? 1.0f : keep_key;
-                    const float pt = __expf(s[4 * gg + i] * p.scale - mm[i]) * k * zz[i];
-                    s[4 * gg + i] = pt * (g[4 * gg + i] - dd[i]);          // dS[q][key]
-                    g[4 * gg + i] = pt + c * zz[i];                         // out[q][key]
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const bf16x8 dsf = pack8(s, 8 * st), pf = pack8(g, 8 * st);
-#pragma unroll
-                for (int dt = 0; dt < DW; ++dt) {
-                    const int dbase = (SPLITD ? dp : dt) * 32;
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tA, t * 32 + 16 * st, dbase, lane), dsf, dk[dt], 0, 0, 0);
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tB, t * 32 + 16 * st, dbase, lane), pf, dv[dt], 0, 0, 0);
-                }
-            }
-        }
-        if (key < N) {
-            bf16_t* krow = p.dqkv + ((size_t)b * N + key) * p.ld + p.D + h * HD;
-            bf16_t* vrow = krow + p.D;
-#pragma unroll
-            for (int dt = 0; dt < DW; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = (SPLITD ? dp : dt) * 32 + 8 * g + 4 * hh;
-                    if (d < HD) {
-                        *reinterpret_cast<uint2*>(krow + d) = make_uint2(pack_bf16x2(dk[dt][4 * g] * p.scale, dk[dt][4 * g + 1] * p.scale),
-                                                                         pack_bf16x2(dk[dt][4 * g + 2] * p.scale, dk[dt][4 * g + 3] * p.scale));
-                        *reinterpret_cast<uint2*>(vrow + d) = make_uint2(pack_bf16x2(dv[dt][4 * g], dv[dt][4 * g + 1]), pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]));
-                    }
-                }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ backward, one pass
 // Every (query tile, key tile) pair is visited ONCE: wave w owns key tile w (its K / V fragments stay in registers, dK / dV
 // accumulate in registers) and walks the query tiles in the rotated order t = (w + i) mod NT, so that in step i the NT waves work on
@@ -965,28 +772,15 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
-    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 4;
+    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 1;
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
         constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
-        if (fused == 4) {       // one pass over the (query tile, key tile) pairs
+        if (fused) {            // one pass over the (query tile, key tile) pairs (PPF_ATTN_BWD_FUSED=0: the two-kernel form dq + dkv)
             constexpr int lds_bytes = OnePassLds<HDv, NTv>::BYTES;
             auto kern = attn_bwd_onepass_kernel<HDv, NTv>;
             static bool attr_set = false;                  // one flag per instantiation (the lambda is instantiated per (hd, nt))
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-                if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(1, H, B), dim3(G::NTHR), lds_bytes, stream, p);
-            PPF_LAUNCH_CHECK();
-            return 0;
-        }
-        if (fused) {            // one launch, two phases over the staged tiles (PPF_ATTN_BWD_FUSED=1; 0: the two-kernel form)
-            constexpr int lds_bytes = 4 * NTv * 32 * 128 + 4 * NTv * 32 * 4;
-            auto kern = attn_bwd_fused_kernel<HDv, NTv, 2, false>;
-            static bool attr_set = false;
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
                 if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }

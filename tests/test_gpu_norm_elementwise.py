@@ -121,3 +121,21 @@ def test_adamw_matches_torch():
         _lib.call("ppf_adamw_step", p, gr.cuda(), m, v, ema, p16, n, 2, bounds.data_ptr(), lr.data_ptr(), wd.data_ptr(), 0.9, 0.999, 1e-8, step, 0.99, 1.0)
     assert_close(p, pr.detach(), rtol=1e-5, atol=1e-6, what="adamw params")
     assert_close(p16.float(), p.bfloat16().float().cpu(), rtol=0, atol=0, what="bf16 recast")
+
+
+def test_axpbypcz_and_loss_fn_backward_constants():
+    """loss = ce + c1 cov + c2 mean in one launch; seeded with the cached one the backward hands out cached constants (no launches)."""
+    import torch
+    from protopformer_amd import ops
+    from protopformer_amd.protopformer import WeightedLossFn
+    x, y, z = (torch.randn(5, device="cuda") for _ in range(3))
+    out = ops.axpbypcz(x, y, z, 1.0, 0.1, 0.5)
+    assert torch.allclose(out, x + 0.1 * y + 0.5 * z, rtol=1e-6, atol=1e-6)
+    ce, cov, mean = (torch.tensor(v, device="cuda", requires_grad=True) for v in (2.0, 3.0, 4.0))
+    loss = WeightedLossFn.apply(ce, cov, mean, 0.1, 0.5)
+    assert abs(float(loss) - (2.0 + 0.3 + 2.0)) < 1e-6
+    loss.backward(gradient=ops.const_scalar(loss.device, 1.0))
+    assert float(ce.grad) == 1.0 and abs(float(cov.grad) - 0.1) < 1e-7 and float(mean.grad) == 0.5
+    ce2, cov2, mean2 = (torch.tensor(v, device="cuda", requires_grad=True) for v in (2.0, 3.0, 4.0))
+    (WeightedLossFn.apply(ce2, cov2, mean2, 0.1, 0.5) * 2.0).backward()             # generic upstream gradient
+    assert float(ce2.grad) == 2.0 and abs(float(cov2.grad) - 0.2) < 1e-6 and float(mean2.grad) == 1.0
