@@ -253,7 +253,7 @@ def deit_backward(ppnet, store, saved, df):
     Dp = conv.out_channels
     # add-on: sigmoid' then the two GEMMs
     lane = wgrad_lane(store)
-    lnb = functools.partial(ops.layernorm_bwd, lane=lane)      # column-sum reductions (parameter grads) go to the side stream
+    lnb = functools.partial(ops.layernorm_bwd, lane=lane, defer_reduce=True)      # column-sum reductions (parameter grads): side stream
     dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), store.grad_view(conv.bias))
     _wgrad(store, dz, head["nf"], conv.weight)
     dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)

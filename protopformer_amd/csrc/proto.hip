@@ -152,7 +152,7 @@ __device__ __forceinline__ Split3 split3(float lo, float hi) {
 __device__ __forceinline__ int p6_off(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }   // 128-byte rows, chunk swizzle
 
 template <int TT, bool POOL>
-__global__ __launch_bounds__(256, 3) void proto_fwd6_kernel(const ProtoFwdParams p) {
+__global__ __launch_bounds__(256, TT <= 3 ? 3 : 2) void proto_fwd6_kernel(const ProtoFwdParams p) {
     constexpr int ROWS = TT * 32, BK6 = 64;
     constexpr int PLANE = ROWS * 128;                              // bytes: [ROWS][64 bf16], one piece
     constexpr int STAGE = 3 * PLANE / 4;                           // floats
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void proto_fwd6_kernel(const ProtoFwdParams
 }
 
 template <int TT, bool POOL>
-__global__ __launch_bounds__(256, PPF_PROTO_OCC) void proto_fwd_kernel(const ProtoFwdParams p) {
+__global__ __launch_bounds__(256, TT <= 3 ? PPF_PROTO_OCC : 2) void proto_fwd_kernel(const ProtoFwdParams p) {
     constexpr int ROWS = TT * 32;
     constexpr int STAGE = (ROWS + PB) * LDP;                       // floats
     constexpr int XPOSE = 4 * 16 * (ROWS + 1);                     // per-wave [16 p][ROWS+1] transpose tiles (two halves per map): with
@@ -730,7 +730,8 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
         constexpr int NJ = decltype(njc)::value;
         if (dtok) {
             hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(W, B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
-            if (W <= 64) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 1>), dim3(B * T), dim3(64), 0, stream, p, (const uint32_t*)workspace, W);
+            static const int tok_nw = getenv("PPF_PROTO_TOK_NW") ? atoi(getenv("PPF_PROTO_TOK_NW")) : 1;
+            if (W <= 64 && tok_nw == 1) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 1>), dim3(B * T), dim3(64), 0, stream, p, (const uint32_t*)workspace, W);
             else hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 8>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
         }
         if (dprotos) {
