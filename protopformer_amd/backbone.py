@@ -160,7 +160,6 @@ class WgradLane:
         nl = int(os.environ.get("PPF_LANES", "1"))
         self.streams = [torch.cuda.Stream(device=device) for _ in range(nl)] if self.enabled else []
         self.raws = [st.cuda_stream for st in self.streams]
-        self._rr = 0
         self.last_read = {}         # data_ptr of a tracked buffer -> ticket of the last side-stream launch that reads it
         self.tracked = set()
         self.held = []              # tensors the lane reads, kept alive (so their memory is not reused) until the next join()
@@ -179,14 +178,15 @@ class WgradLane:
         self.pending.append((fn, reads))
         self.held.extend(reads)
         if not defer:
-            self.flush()
+            self.flush(tag)
 
-    def flush(self):
+    def flush(self, tag=None):
         if not self.pending:
             return
         L = _lib.lib()
-        raw = self.raws[self._rr]
-        self._rr = (self._rr + 1) % len(self.raws)
+        # lane 0 carries the weight gradients; the long prototype-gradient kernels at the start of backward (tag "PROTO") get a lane
+        # of their own when there is one, so that the first weight gradients do not queue behind them
+        raw = self.raws[1] if (tag == "PROTO" and len(self.raws) > 1) else self.raws[0]
         if L.ppf_stream_wait_stream(raw, _lib.stream_ptr()):
             raise RuntimeError(L.ppf_last_error().decode())
         _lib.push_stream(raw)

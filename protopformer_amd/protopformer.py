@@ -53,6 +53,9 @@ def build_features(base_architecture, pretrained=False, img_size=224, drop_path=
 
 
 # ------------------------------------------------------------------------------------------------ autograd nodes
+_SIDE_FIRST = os.environ.get("PPF_PROTO_SIDE_FIRST", "1") != "0"
+
+
 class ProtoLayerFn(torch.autograd.Function):
     """get_activations for both branches (protopformer.py:236-247, 311-312)."""
 
@@ -92,15 +95,26 @@ class ProtoLayerFn(torch.autograd.Function):
             gf = g_full.contiguous() if g_full is not None else None
             gl = g_l.contiguous() if g_l is not None else None
             pl = protos_local.reshape(-1, Dp)
+            # the side stream starts on the prototype gradients BEFORE the main stream's token-gradient kernels are enqueued: the two
+            # only share inputs, and the lane orders itself behind whatever the main stream has enqueued at submit time
+            side_l = lambda: ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, None, store.grad_view(protos_local).reshape(-1, Dp),
+                                           act_kind, ppnet.epsilon)
+            reads_l = [t for t in (f, dist, gf, gl, argmax) if t is not None]
+            if _SIDE_FIRST:
+                lane.submit(side_l, reads_l, tag="PROTO")
             ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, df, None, act_kind, ppnet.epsilon)
-            lane.submit(lambda: ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, None, store.grad_view(protos_local).reshape(-1, Dp),
-                                              act_kind, ppnet.epsilon), [t for t in (f, dist, gf, gl, argmax) if t is not None], tag="PROTO")
+            if not _SIDE_FIRST:
+                lane.submit(side_l, reads_l, tag="PROTO")
         if g_g is not None:
             gg = g_g.contiguous()
             pg = protos_global.reshape(-1, Dp)
+            side_g = lambda: ops.proto_bwd(f, 0, 1, pg, dist_g, None, gg, None, None, store.grad_view(protos_global).reshape(-1, Dp),
+                                           act_kind, ppnet.epsilon)
+            if _SIDE_FIRST:
+                lane.submit(side_g, (f, dist_g, gg), tag="PROTO")
             ops.proto_bwd(f, 0, 1, pg, dist_g, None, gg, None, df, None, act_kind, ppnet.epsilon)
-            lane.submit(lambda: ops.proto_bwd(f, 0, 1, pg, dist_g, None, gg, None, None, store.grad_view(protos_global).reshape(-1, Dp),
-                                              act_kind, ppnet.epsilon), (f, dist_g, gg), tag="PROTO")
+            if not _SIDE_FIRST:
+                lane.submit(side_g, (f, dist_g, gg), tag="PROTO")
         return df, None, None, None, None
 
 
