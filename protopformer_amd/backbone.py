@@ -84,10 +84,15 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     Nc, eps_n = N, 0                              # tokens per sample in the current block, N of the softmax eps term (0 = Nc)
     x = x.reshape(B * N, D)
     lane = wgrad_lane(store)
+    rolled = None                                 # rollout outputs when the chain itself ran on the side stream
+    roll_side = reserve_layer > 0 and os.environ.get("PPF_ROLLOUT_CHAIN_SIDE", "1") != "0"
     for i, blk in enumerate(feats.blocks):
         if i == reserve_layer:
             lane.join()
-            cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None)
+            if rolled is not None:
+                cls_attn, idx, policy = rolled
+            else:
+                cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None)
             if compact:
                 rows = ops.reserved_rows_map(idx, N)
                 x = ops.gather_rows(x, rows)
@@ -104,6 +109,12 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
                 if side_thr:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
             lane.submit(side, (qkv, rowmax, zinv, hm, thr))
+            if roll_side and i == reserve_layer - 1:
+                # the rollout chain (176 us, one workgroup per sample) depends only on the head-mean maps and thresholds the lane has
+                # produced: it runs there, right behind the last map, under the rest of this block instead of in front of the next one
+                rolled = ops.rollout_outputs(B, N, reserve_k, 1, x.device)
+                lane.submit(lambda: ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, out=rolled),
+                            (hm, thr) + rolled)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
         n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)

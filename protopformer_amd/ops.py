@@ -162,14 +162,19 @@ def rollout_threshold(hm_layer, thr_out, N, discard_ratio=0.9):
     _lib.call("ppf_rollout_threshold", hm_layer, B, N, NP, int(N * N * discard_ratio), thr_out)
 
 
-def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None):
-    """hm: [L,B,N,NP] fp32 head-mean attention. Returns (cls_attn [B,N-lead], idx int32 [B,k] ascending, policy [B,N-lead+1])."""
+def rollout_outputs(B, N, k, lead, device):
+    """(cls_attn [B,N-lead], idx int32 [B,k], policy [B,N-lead+1]) buffers for rollout(out=...)."""
+    Nk = N - lead
+    return (torch.empty((B, Nk), dtype=torch.float32, device=device), torch.empty((B, k), dtype=torch.int32, device=device),
+            torch.empty((B, Nk + 1), dtype=torch.float32, device=device))
+
+
+def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None, out=None):
+    """hm: [L,B,N,NP] fp32 head-mean attention. Returns (cls_attn [B,N-lead], idx int32 [B,k] ascending, policy [B,N-lead+1]);
+    out = rollout_outputs(...) to write into existing buffers (no allocation: usable on the side-stream lane)."""
     _chk(hm, torch.float32)
     NP = hm.shape[-1]
-    Nk = N - lead
-    cls_attn = torch.empty((B, Nk), dtype=torch.float32, device=hm.device)
-    idx = torch.empty((B, k), dtype=torch.int32, device=hm.device)
-    policy = torch.empty((B, Nk + 1), dtype=torch.float32, device=hm.device)
+    cls_attn, idx, policy = out if out is not None else rollout_outputs(B, N, k, lead, hm.device)
     n_init = init_rows.shape[0] if init_rows is not None else 0
     # discard counts in double precision, exactly like the reference's int(numel * ratio)
     kdrop, kdrop_init = int(N * N * discard_ratio), int((N + 1) * discard_ratio)
