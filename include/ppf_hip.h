@@ -163,6 +163,14 @@ int ppf_cross_entropy(const float* logits, const void* label_i64, float* per_sam
 /* last_layer / last_layer_global (protopformer.py:126-131, 314-316): C = alpha * A B^T + beta * C, arbitrary strides */
 int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk,
               int ldc, float alpha, float beta, float* workspace, int64_t workspace_floats, ppf_stream_t stream);
+/* Two such products with the same M in one launch + one ordered reduction: out_i = alpha_i A_i B_i^T (may be NULL) and
+ * sum = c0 A0 B0^T + c1 A1 B1^T (may be NULL; N0 == N1): logits = g * logits_global + (1 - g) * logits_local (protopformer.py:314-316)
+ * and the two input gradients of that layer. */
+int64_t ppf_sgemm_pair_workspace(int M, int N0, int K0, int N1, int K1);
+int ppf_sgemm_pair(const float* A0, const float* B0, float* out0, int N0, int K0, int64_t sam0, int64_t sak0, int64_t sbn0, int64_t sbk0,
+                   int ldo0, float alpha0, const float* A1, const float* B1, float* out1, int N1, int K1, int64_t sam1, int64_t sak1,
+                   int64_t sbn1, int64_t sbk1, int ldo1, float alpha1, float* sum, int ldsum, float c0, float c1, int M, float* workspace,
+                   int64_t workspace_floats, ppf_stream_t stream);
 int ppf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, ppf_stream_t stream);
 /* out = a x + b y + c z: loss = CE + ppc_cov_coe * cov + ppc_mean_coe * mean in one launch (tools/engine_proto.py:61-64) */
 int ppf_axpbypcz(const float* x, const float* y, const float* z, float* out, float a, float b, float c, int64_t n, ppf_stream_t stream);

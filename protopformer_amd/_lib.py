@@ -35,6 +35,7 @@ SIGS = {
     "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",
     "ppf_cross_entropy": "ppppp" "ii" "s",
     "ppf_sgemm": "ppp" "iii" "llll" "i" "ff" "pl" "s",
+    "ppf_sgemm_pair": "ppp" "ii" "llll" "i" "f" "ppp" "ii" "llll" "i" "f" "p" "i" "ff" "i" "pl" "s",
     "ppf_axpby": "ppp" "ff" "l" "s",
     "ppf_axpbypcz": "pppp" "fff" "l" "s",
     "ppf_topk_sorted": "piiips",
@@ -84,6 +85,8 @@ def lib():
         _lib.ppf_abi_version.restype = ctypes.c_int
         _lib.ppf_gemm_workspace_bytes.restype = ctypes.c_size_t
         _lib.ppf_gemm_workspace_bytes.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_sgemm_pair_workspace.restype = ctypes.c_int64
+        _lib.ppf_sgemm_pair_workspace.argtypes = [ctypes.c_int] * 5
         _lib.ppf_proto_bwd_single_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_bwd_single_workspace.argtypes = [ctypes.c_int] * 3
         _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int

@@ -190,6 +190,64 @@ __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restri
     *c = alpha * s + (beta != 0.f ? beta * *c : 0.f);
 }
 
+// Two independent strided fp32 products P_i = A_i B_i^T (same M) in ONE launch + ONE ordered reduction: the class-connection
+// layers of the global and the local branch (protopformer.py:314-316) and their input gradients.  Slices of both problems share the
+// grid (blockIdx.z < S0: problem 0); the reduction writes out_i = alpha_i P_i and, when asked, sum = c0 P0 + c1 P1.
+struct SgemmProb {
+    const float* A; const float* B; float* out;
+    int N, K, ldo, S, kchunk;
+    int64_t sam, sak, sbn, sbk;
+    float alpha, c;
+    int64_t part_off;          // floats: first partial slice of this problem
+};
+__global__ __launch_bounds__(256) void sgemm_pair_kernel(const SgemmProb q0, const SgemmProb q1, float* __restrict__ part, int M) {
+    __shared__ float sa[32][33], sb[32][33];
+    const bool second = (int)blockIdx.z >= q0.S;
+    const SgemmProb& q = second ? q1 : q0;
+    const int z = second ? blockIdx.z - q0.S : blockIdx.z;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (n0 >= q.N) return;
+    const int kbeg = z * q.kchunk, kend = min(q.K, kbeg + q.kchunk);
+    const bool a_kfast = q.sak == 1, b_kfast = q.sbk == 1;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            int r, k;
+            if (a_kfast) { k = i & 31; r = i >> 5; } else { r = i & 31; k = i >> 5; }
+            sa[r][k] = (m0 + r < M && k0 + k < kend) ? q.A[(size_t)(m0 + r) * q.sam + (size_t)(k0 + k) * q.sak] : 0.f;
+            if (b_kfast) { k = i & 31; r = i >> 5; } else { r = i & 31; k = i >> 5; }
+            sb[r][k] = (n0 + r < q.N && k0 + k < kend) ? q.B[(size_t)(n0 + r) * q.sbn + (size_t)(k0 + k) * q.sbk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = sa[ty][k], a1 = sa[ty + 16][k], b0 = sb[tx][k], b1 = sb[tx + 16][k];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        __syncthreads();
+    }
+    float* dst = part + q.part_off + (size_t)z * M * q.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < q.N) dst[(size_t)m * q.N + n] = acc[i][j];
+        }
+}
+__global__ __launch_bounds__(256) void sgemm_pair_reduce_kernel(const SgemmProb q0, const SgemmProb q1, const float* __restrict__ part, float* __restrict__ sum,
+                                                                int ldsum, int M) {
+    const int nmax = q0.N > q1.N ? q0.N : q1.N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * nmax) return;
+    const int m = i / nmax, n = i - m * nmax;
+    float p0 = 0.f, p1 = 0.f;
+    if (n < q0.N) { for (int z = 0; z < q0.S; ++z) p0 += part[q0.part_off + ((size_t)z * M + m) * q0.N + n]; if (q0.out) q0.out[(size_t)m * q0.ldo + n] = q0.alpha * p0; }
+    if (n < q1.N) { for (int z = 0; z < q1.S; ++z) p1 += part[q1.part_off + ((size_t)z * M + m) * q1.N + n]; if (q1.out) q1.out[(size_t)m * q1.ldo + n] = q1.alpha * p1; }
+    if (sum) sum[(size_t)m * ldsum + n] = q0.c * p0 + q1.c * p1;
+}
+
 __global__ __launch_bounds__(256) void axpbypcz_kernel(const float* x, const float* y, const float* z, float* out, float a, float b, float c, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a * x[i] + b * y[i] + c * z[i];
 }
@@ -253,6 +311,35 @@ int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, in
         hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, workspace, C, M, N, ldc, S, alpha, beta);
         PPF_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// Two products with the same M in one launch + one ordered reduction (see sgemm_pair_kernel):  out_i = alpha_i A_i B_i^T (i = 0, 1;
+// out_i may be NULL), sum = c0 A0 B0^T + c1 A1 B1^T (may be NULL; needs N0 == N1).  A_i(m, k) = A_i[m*sam_i + k*sak_i],
+// B_i(n, k) = B_i[n*sbn_i + k*sbk_i].  workspace: ppf_sgemm_pair_workspace(M, N0, K0, N1, K1) floats.
+static int pair_slices(int K) { int S = (K + 127) / 128; if (S > 16) S = 16; if (S < 1) S = 1; const int kc = ((K + S - 1) / S + 31) / 32 * 32; return (K + kc - 1) / kc; }
+int64_t ppf_sgemm_pair_workspace(int M, int N0, int K0, int N1, int K1) {
+    return (int64_t)M * ((int64_t)N0 * pair_slices(K0) + (int64_t)N1 * pair_slices(K1));
+}
+int ppf_sgemm_pair(const float* A0, const float* B0, float* out0, int N0, int K0, int64_t sam0, int64_t sak0, int64_t sbn0, int64_t sbk0, int ldo0,
+                   float alpha0, const float* A1, const float* B1, float* out1, int N1, int K1, int64_t sam1, int64_t sak1, int64_t sbn1,
+                   int64_t sbk1, int ldo1, float alpha1, float* sum, int ldsum, float c0, float c1, int M, float* workspace,
+                   int64_t workspace_floats, hipStream_t stream) {
+    PPF_CHECK_ARG(M > 0 && N0 > 0 && K0 > 0 && N1 > 0 && K1 > 0 && A0 && B0 && A1 && B1, PPF_ERR_SHAPE, "ppf_sgemm_pair: bad shape / null operand");
+    PPF_CHECK_ARG(sum == nullptr || N0 == N1, PPF_ERR_ARG, "ppf_sgemm_pair: the combined output needs N0 == N1");
+    PPF_CHECK_ARG(workspace && workspace_floats >= ppf_sgemm_pair_workspace(M, N0, K0, N1, K1), PPF_ERR_ARG,
+                  "ppf_sgemm_pair: workspace below ppf_sgemm_pair_workspace() = %lld floats", (long long)ppf_sgemm_pair_workspace(M, N0, K0, N1, K1));
+    SgemmProb q0, q1;
+    q0.A = A0; q0.B = B0; q0.out = out0; q0.N = N0; q0.K = K0; q0.ldo = ldo0; q0.sam = sam0; q0.sak = sak0; q0.sbn = sbn0; q0.sbk = sbk0; q0.alpha = alpha0; q0.c = c0;
+    q1.A = A1; q1.B = B1; q1.out = out1; q1.N = N1; q1.K = K1; q1.ldo = ldo1; q1.sam = sam1; q1.sak = sak1; q1.sbn = sbn1; q1.sbk = sbk1; q1.alpha = alpha1; q1.c = c1;
+    q0.S = pair_slices(K0); q0.kchunk = ((K0 + q0.S - 1) / q0.S + 31) / 32 * 32;
+    q1.S = pair_slices(K1); q1.kchunk = ((K1 + q1.S - 1) / q1.S + 31) / 32 * 32;
+    q0.part_off = 0; q1.part_off = (int64_t)M * N0 * q0.S;
+    const int nmax = N0 > N1 ? N0 : N1;
+    hipLaunchKernelGGL(sgemm_pair_kernel, dim3((nmax + 31) / 32, (M + 31) / 32, q0.S + q1.S), dim3(256), 0, stream, q0, q1, workspace, M);
+    PPF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sgemm_pair_reduce_kernel, dim3((M * nmax + 255) / 256), dim3(256), 0, stream, q0, q1, workspace, sum, ldsum, M);
+    PPF_LAUNCH_CHECK();
     return 0;
 }
 

@@ -244,6 +244,16 @@ def sgemm(a, b, out, M, N, K, sam, sak, sbn, sbk, alpha=1.0, beta=0.0):
     return out
 
 
+def sgemm_pair(a0, b0, out0, N0, K0, sa0, sb0, alpha0, a1, b1, out1, N1, K1, sa1, sb1, alpha1, M, total=None, c0=0.0, c1=0.0):
+    """out_i = alpha_i A_i B_i^T (i = 0, 1) and total = c0 A0 B0^T + c1 A1 B1^T in one launch + one reduction; sa_i = (row stride, k stride)
+    of A_i, sb_i = (row stride, k stride) of B_i (B_i indexed [n, k])."""
+    nfl = _lib.lib().ppf_sgemm_pair_workspace(M, N0, K0, N1, K1)
+    ws = _workspace(a0.device, nfl * 4)
+    _lib.call("ppf_sgemm_pair", a0, b0, out0, N0, K0, sa0[0], sa0[1], sb0[0], sb0[1], out0.shape[-1] if out0 is not None else 0, float(alpha0),
+              a1, b1, out1, N1, K1, sa1[0], sa1[1], sb1[0], sb1[1], out1.shape[-1] if out1 is not None else 0, float(alpha1),
+              total, total.shape[-1] if total is not None else 0, float(c0), float(c1), M, ws, ws.numel() // 4)
+
+
 def axpbypcz(x, y, z, a, b, c):
     out = torch.empty_like(x)
     _lib.call("ppf_axpbypcz", x, y, z, out, float(a), float(b), float(c), x.numel())

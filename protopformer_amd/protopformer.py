@@ -126,9 +126,9 @@ class LogitsFn(torch.autograd.Function):
         B, C = act_g.shape[0], w_g.shape[0]
         lg = torch.empty((B, C), dtype=torch.float32, device=act_g.device)
         ll = torch.empty_like(lg)
-        ops.sgemm(act_g, w_g, lg, B, C, act_g.shape[1], act_g.shape[1], 1, w_g.shape[1], 1)
-        ops.sgemm(act_l, w_l, ll, B, C, act_l.shape[1], act_l.shape[1], 1, w_l.shape[1], 1)
-        logits = ops.axpby(lg, ll, coe, 1.0 - coe)
+        logits = torch.empty_like(lg)
+        ops.sgemm_pair(act_g, w_g, lg, C, act_g.shape[1], (act_g.shape[1], 1), (w_g.shape[1], 1), 1.0,
+                       act_l, w_l, ll, C, act_l.shape[1], (act_l.shape[1], 1), (w_l.shape[1], 1), 1.0, B, total=logits, c0=coe, c1=1.0 - coe)
         ctx.save_for_backward(w_g, w_l)
         ctx.coe = coe
         ctx.mark_non_differentiable(lg, ll)
@@ -141,8 +141,9 @@ class LogitsFn(torch.autograd.Function):
         B, C = dlogits.shape
         dg = torch.empty((B, w_g.shape[1]), dtype=torch.float32, device=dlogits.device)
         dl = torch.empty((B, w_l.shape[1]), dtype=torch.float32, device=dlogits.device)
-        ops.sgemm(dlogits, w_g, dg, B, w_g.shape[1], C, C, 1, 1, w_g.shape[1], alpha=ctx.coe)
-        ops.sgemm(dlogits, w_l, dl, B, w_l.shape[1], C, C, 1, 1, w_l.shape[1], alpha=1.0 - ctx.coe)
+        # dg[b, p] = coe * sum_c dlogits[b, c] W_g[c, p]: "B" operand indexed [n = p, k = c] -> strides (1, P)
+        ops.sgemm_pair(dlogits, w_g, dg, w_g.shape[1], C, (C, 1), (1, w_g.shape[1]), ctx.coe,
+                       dlogits, w_l, dl, w_l.shape[1], C, (C, 1), (1, w_l.shape[1]), 1.0 - ctx.coe, B)
         return dg, dl, None, None, None
 
 

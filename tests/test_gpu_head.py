@@ -195,3 +195,24 @@ def test_proto_bwd_single_token_dense_form(B, Dp, P, kind):
     assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens (dense form)")
     assert float(dtok[:, 0].abs().max()) == 0.0 and float(dtok[:, 2].abs().max()) == 0.0        # only the token row is written
     assert_close(dpro - 0.25, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes (dense form, accumulated)")
+
+
+def test_sgemm_pair_matches_two_products():
+    """ppf_sgemm_pair: both class-connection products, their scaled copies and the weighted sum in one launch + one reduction."""
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, P0, P1 = 37, 200, 980, 1960
+    a0, a1 = torch.rand(B, P0, generator=g).cuda(), torch.rand(B, P1, generator=g).cuda()
+    w0, w1 = torch.randn(C, P0, generator=g).cuda(), torch.randn(C, P1, generator=g).cuda()
+    o0, o1, tot = (torch.empty(B, C, device="cuda") for _ in range(3))
+    ops.sgemm_pair(a0, w0, o0, C, P0, (P0, 1), (P0, 1), 1.0, a1, w1, o1, C, P1, (P1, 1), (P1, 1), 1.0, B, total=tot, c0=0.3, c1=0.7)
+    r0, r1 = a0.double() @ w0.double().t(), a1.double() @ w1.double().t()
+    assert_close(o0, r0.float(), rtol=1e-5, atol=1e-3, what="first product")
+    assert_close(o1, r1.float(), rtol=1e-5, atol=1e-3, what="second product")
+    assert_close(tot, (0.3 * r0 + 0.7 * r1).float(), rtol=1e-5, atol=1e-3, what="weighted sum")
+    # input gradients: different N per problem, no sum
+    d = torch.randn(B, C, generator=g).cuda()
+    g0, g1 = torch.empty(B, P0, device="cuda"), torch.empty(B, P1, device="cuda")
+    ops.sgemm_pair(d, w0, g0, P0, C, (C, 1), (1, P0), 0.3, d, w1, g1, P1, C, (C, 1), (1, P1), 0.7, B)
+    assert_close(g0, (0.3 * d.double() @ w0.double()).float(), rtol=1e-5, atol=1e-4, what="d act global")
+    assert_close(g1, (0.7 * d.double() @ w1.double()).float(), rtol=1e-5, atol=1e-4, what="d act local")
