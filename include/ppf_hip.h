@@ -29,6 +29,10 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 #define PPF_ERR_ALIGN (-2)
 #define PPF_ERR_ARG (-3)
 
+/* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
+ * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
+#define PPF_ABI_VERSION 3
+
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
 int ppf_abi_version(void);

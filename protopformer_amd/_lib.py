@@ -68,6 +68,8 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
+EXPECTED_ABI = 3               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
 _FAST = {}                     # name -> (bound function, pointer-argument positions, has trailing stream, arity)
@@ -83,6 +85,11 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ppf_last_error.restype = ctypes.c_char_p
         _lib.ppf_abi_version.restype = ctypes.c_int
+        got = _lib.ppf_abi_version()
+        if got != EXPECTED_ABI:
+            _lib = None
+            raise RuntimeError(f"{LIB_PATH} was built for ABI version {got}, this binding expects {EXPECTED_ABI}: rebuild it with "
+                               "`python -m protopformer_amd.build --force` (a stale library would receive shifted arguments)")
         _lib.ppf_gemm_workspace_bytes.restype = ctypes.c_size_t
         _lib.ppf_gemm_workspace_bytes.argtypes = [ctypes.c_int] * 3
         _lib.ppf_sgemm_pair_workspace.restype = ctypes.c_int64

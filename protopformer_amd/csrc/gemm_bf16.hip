@@ -590,6 +590,8 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     PPF_CHECK_ARG(trans_b ? (N % 8 == 0) : (K % 8 == 0), PPF_ERR_ALIGN, "ppf_gemm_bf16: B inner extent must be a multiple of 8");
     PPF_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, PPF_ERR_ALIGN, "ppf_gemm_bf16: pointers must be 16-byte aligned");
     PPF_CHECK_ARG(!(trans_a && !trans_b), PPF_ERR_ARG, "ppf_gemm_bf16: (trans_a=1, trans_b=0) is not instantiated");
+    PPF_CHECK_ARG((((uintptr_t)aux_in | (uintptr_t)aux_out | (uintptr_t)res) & 15) == 0 && (ldaux % 4) == 0 && (ldres % 4) == 0, PPF_ERR_ALIGN,
+                  "ppf_gemm_bf16: aux / residual pointers must be 16-byte aligned, ldaux and ldres multiples of 4 (the epilogues use 8/16-byte accesses)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
@@ -704,6 +706,11 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
     PPF_CHECK_ARG(kpad || (trans_a ? (M % 8 == 0) : (K % 8 == 0)), PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: A inner extent must be a multiple of 8");
     PPF_CHECK_ARG(kpad || (trans_b ? (N % 8 == 0) : (K % 8 == 0)), PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: B inner extent must be a multiple of 8");
     PPF_CHECK_ARG(((sa_o | sa_i | sb_o | sb_i) % 8) == 0 && ((sc_o | sc_i) % 4) == 0, PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: batch strides alignment");
+    // the bf16-output epilogue stores 16 bytes per lane whenever ldc % 8 == 0: every problem's C must then start on a 16-byte boundary
+    PPF_CHECK_ARG(out_f32 || (ldc % 8) != 0 || ((sc_o | sc_i) % 8) == 0, PPF_ERR_ALIGN,
+                  "ppf_gemm_bf16_batched: bf16 output with ldc %% 8 == 0 needs batch strides of C that are multiples of 8 elements (sc_o=%lld sc_i=%lld)",
+                  (long long)sc_o, (long long)sc_i);
+    PPF_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, PPF_ERR_ALIGN, "ppf_gemm_bf16_batched: pointers must be 16-byte aligned");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.rowscale = nullptr; p.rows_per_group = 1; p.colscale = nullptr; p.aux_in = nullptr;

@@ -1,5 +1,6 @@
 // Error channel + version/introspection entry points of the C ABI.
 #include "ppf_common.h"
+#include "ppf_hip.h"
 #include <cstdarg>
 #include <cstdio>
 
@@ -16,7 +17,7 @@ void ppf_set_error(const char* fmt, ...) {
 
 const char* ppf_last_error(void) { return g_err; }
 
-int ppf_abi_version(void) { return 1; }
+int ppf_abi_version(void) { return PPF_ABI_VERSION; }
 
 // Device facts the host side uses for launch sizing and reporting.
 int ppf_device_info(int* cu_count, int* clock_mhz, char* name, int name_len) {

@@ -53,7 +53,9 @@ class Cub2011:
         except OSError as e:
             raise RuntimeError("Dataset not found or corrupted. (no download possible here)") from e
         want = 1 if train else 0
-        self.data = [(i, paths[i], labels[i]) for i in sorted(paths) if split.get(i) == want and i in labels]
+        # pandas inner merges on img_id (tools/datasets.py:427-434): rows stay in the order of images.txt, ids missing from either of
+        # the other two files drop out
+        self.data = [(i, paths[i], labels[i]) for i in paths if split.get(i) == want and i in labels]
         for _, fp, _ in self.data:
             if not os.path.isfile(os.path.join(self.root, self.base_folder, fp)):
                 raise RuntimeError("Dataset not found or corrupted: missing " + fp)

@@ -68,6 +68,7 @@ class FlatAdamW:
         self._hyper = torch.empty(_HY_N, dtype=torch.float32, device=st.device)
         _lib.call("ppf_hyper_set", self._hyper, self._hyper_host.data_ptr(), _HY_N)
         self._clip_partial = None
+        self._clip_issued = False                 # ppf_clip_grad_scale wrote hyper[19] for the step about to be applied
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=st.device)
 
     # ------------------------------------------------------------------ consistency with the model's flat store
@@ -92,7 +93,11 @@ class FlatAdamW:
         h[_HY_BC1] = 1.0 - self.betas[0] ** self.step_count
         h[_HY_BC2] = math.sqrt(1.0 - self.betas[1] ** self.step_count)
         h[_HY_GSCALE] = float(self.grad_scale)
-        _lib.call("ppf_hyper_set", self._hyper, h.data_ptr(), _HY_CLIP)
+        # hyper[19] (clip coefficient) is written on the device by ppf_clip_grad_scale; a step without clipping must not inherit the
+        # previous step's coefficient: the upload then covers it too (host mirror value 1.0)
+        n = _HY_CLIP if self._clip_issued else _HY_N
+        self._clip_issued = False
+        _lib.call("ppf_hyper_set", self._hyper, h.data_ptr(), n)
 
     def clip_grad_norm(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ over all trainable gradients (timm dispatch_clip_grad mode 'norm'), folded into the
@@ -101,6 +106,7 @@ class FlatAdamW:
             self._clip_partial = torch.empty(_lib.lib().ppf_clip_grad_blocks(), dtype=torch.float32, device=self.store.device)
         _lib.call("ppf_clip_grad_scale", self.store.grads, self.store.total, float(max_norm), float(self.grad_scale), self._clip_partial,
                   self._hyper, self.grad_norm)
+        self._clip_issued = True
 
     def launch_update(self):
         st = self.store
@@ -264,6 +270,7 @@ class GradSync:
         self.cuda = flat_grads.is_cuda
         self.stream = torch.cuda.Stream() if (self.cuda and use_side_stream) else None
         self.pending = []
+        self.launched = 0                                     # collectives issued so far (tests: the forced single-rank path really ran)
 
     def chunk_ready(self, c, also=()):
         """Launch the all-reduce of chunk c: every kernel that writes it has been enqueued on the current stream or on one of
@@ -275,6 +282,7 @@ class GradSync:
         if hi <= lo:
             return
         view = self.g[lo:hi]
+        self.launched += 1
         if self.stream is not None:
             evs = []
             for st in (torch.cuda.current_stream(),) + tuple(s_ for s_ in also if s_ is not None):
@@ -317,7 +325,7 @@ def broadcast_replica_state(ppnet, optimizer=None, src=0):
             dist.broadcast(optimizer.exp_avg, src)
             dist.broadcast(optimizer.exp_avg_sq, src)
             if optimizer.ema is not None:
-                optimizer.ema.copy_(st.params)
+                dist.broadcast(optimizer.ema, src)            # rank src's EMA survives (a checkpoint restored before make_grad_sync)
     st.invalidate()
 
 
@@ -404,6 +412,20 @@ class GraphedTrainStep:
         self.static_in = None
         self.out = None
 
+    def check_matches(self, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss, max_norm):
+        """The captured graph bakes in the `epoch >= 20` branch (PPC terms added or not, engine_proto.py:61-64), the PPC coefficients
+        and whether gradients are clipped.  A step function built for one phase must not be replayed in the other: raise, so that the
+        caller builds a new GraphedTrainStep (e.g. one for epochs < 20 and one from epoch 20 on)."""
+        kw = self.kw
+        want = dict(ppc_branch=bool(use_ppc_loss) and epoch >= 20, use_ppc_loss=bool(use_ppc_loss), max_norm=max_norm)
+        have = dict(ppc_branch=bool(kw["use_ppc_loss"]) and kw["epoch"] >= 20, use_ppc_loss=bool(kw["use_ppc_loss"]), max_norm=kw["max_norm"])
+        if want["ppc_branch"]:
+            want.update(ppc_cov_coe=float(ppc_cov_coe), ppc_mean_coe=float(ppc_mean_coe))
+            have.update(ppc_cov_coe=float(kw["ppc_cov_coe"]), ppc_mean_coe=float(kw["ppc_mean_coe"]))
+        if want != have:
+            raise RuntimeError(f"GraphedTrainStep was built for {have} but train_one_epoch(epoch={epoch}) needs {want}: "
+                               "build a new GraphedTrainStep for this phase (the branch is baked into the captured graph)")
+
     def _capture(self, samples, targets):
         opt = self.optimizer
         self.static_in = (samples, targets) if self.adopt_inputs else (samples.clone(), targets.clone())
@@ -443,6 +465,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, arg
     mean_coe = 0.5 if args is None else getattr(args, "ppc_mean_coe", 0.5)
     if max_norm is None and args is not None:
         max_norm = getattr(args, "clip_grad", None)
+    if step_fn is not None:
+        step_fn.check_matches(epoch=epoch, ppc_cov_coe=cov_coe, ppc_mean_coe=mean_coe, use_ppc_loss=use_ppc, max_norm=max_norm)
     total, n = 0.0, 0
     for it, (samples, targets) in enumerate(data_loader):
         samples = samples.to(device, non_blocking=True)

@@ -261,9 +261,19 @@ def consistency_score(ppnet, loader, parts, image_sizes, num_classes=200, part_t
         cols = (t.to(pa.device) * ppc)[:, None] + torch.arange(ppc, device=pa.device)[None, :]
         acts.append(torch.gather(pa, 1, cols[:, :, None, None].expand(-1, -1, pa.shape[-2], pa.shape[-1])).cpu())
         attn.append(ta.cpu()); targets.append(t.cpu()); ids.append(torch.as_tensor(i).cpu())
-    attn, acts, targets, ids = torch.cat(attn), torch.cat(acts), torch.cat(targets).numpy(), torch.cat(ids).numpy()
-    grid = expand_to_grid(acts.float(), attn.float(), k).numpy() if k != attn.shape[-1] else acts.numpy()
-    effects = []
+    return consistency_from_outputs(torch.cat(attn), torch.cat(acts), torch.cat(targets).numpy(), torch.cat(ids).numpy(), parts, image_sizes, k,
+                                    img_size, num_classes, part_thresh, half_size, n_parts)[0]
+
+
+def consistency_from_outputs(attn, acts, targets, ids, parts, image_sizes, k, img_size, num_classes=200, part_thresh=0.8, half_size=36, n_parts=15):
+    """eval_interpretability.py:152-290 on collected push_forward outputs: attn (B, Np) rollout scores, acts (B, ppc, s, s) the class's
+    own prototype activations on the k = s*s reserved tokens, targets / ids (B,).  Returns (score, effect per (class, prototype),
+    best part fraction per (class, prototype), activations on the patch grid).  Classes without a test image are skipped (the
+    reference's loop assumes every class has one)."""
+    attn, acts = torch.as_tensor(attn), torch.as_tensor(acts)
+    targets, ids = np.asarray(targets), np.asarray(ids)
+    grid = expand_to_grid(acts.float(), attn.float(), k).numpy() if k != attn.reshape(attn.shape[0], -1).shape[-1] else acts.numpy()
+    effects, max_parts = [], []
     for c in range(num_classes):
         sel = np.nonzero(targets == c)[0]
         if sel.size == 0:
@@ -274,7 +284,8 @@ def consistency_score(ppnet, loader, parts, image_sizes, num_classes=200, part_t
             mask, labels = np.zeros(n_parts), []
             for pid, x, y in parts.id_to_part_loc.get(int(ids[j]), []):
                 mask[pid - 1] = 1
-                labels.append((pid - 1, int(img_size * x / w), int(img_size * y / h)))
+                labels.append((pid - 1, int(img_size * (x / w)), int(img_size * (y / h))))
             tables.append(prototype_part_table(grid[j], labels, img_size, half_size, n_parts)); masks.append(mask)
-        effects.extend(consistency_from_tables(tables, masks, part_thresh)[0])
-    return float(np.mean(effects)) if effects else 0.0
+        e, m = consistency_from_tables(tables, masks, part_thresh)
+        effects.extend(e); max_parts.extend(m)
+    return (float(np.mean(effects)) if effects else 0.0), effects, max_parts, grid

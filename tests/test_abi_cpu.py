@@ -44,7 +44,9 @@ def test_binding_table_matches_header(lib):
 
 def test_error_channel_without_gpu(lib):
     lib.ppf_last_error.restype = ctypes.c_char_p
-    assert lib.ppf_abi_version() == 1
+    from protopformer_amd import _lib
+    want = int(re.search(r"#define\s+PPF_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.ppf_abi_version() == want == _lib.EXPECTED_ABI
     # argument validation happens before any device call: a bad shape is reported through the error channel
     rc = lib.ppf_cast_f32_bf16(None, None, ctypes.c_int64(7), None)
     assert rc == -1 and b"multiple of 8" in lib.ppf_last_error()

@@ -132,3 +132,55 @@ def test_preprocess_round_trip():
     y = preprocess_input_function(x)
     assert torch.allclose(y[:, 1], (x[:, 1] - 0.456) / 0.224)
     assert torch.allclose(undo_preprocess_input_function(y), x, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- pinned to the reference
+def _golden_index():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_index.json")))
+
+
+@pytest.fixture(scope="module")
+def mini_root(tmp_path_factory):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import mini_trees as M
+    root = str(tmp_path_factory.mktemp("mini"))
+    M.build_cub(root); M.build_cars(root); M.build_dogs(os.path.join(root, "dogs"))
+    return root
+
+
+def test_index_classes_equal_the_reference_tables(mini_root):
+    """tests/golden/data_index.json holds what /root/reference/tools/datasets.py's Cub2011 / StanfordCars / Dogs returned on the same
+    miniature trees (tests/golden/make_golden_data.py): sample order, relative paths, 0-based labels, image sizes after the dataset's
+    own cropping, class names and per-class counts must all agree."""
+    from protopformer_amd.data import Cub2011, Dogs, StanfordCars
+    gold = _golden_index()
+    for train in (True, False):
+        ds = Cub2011(mini_root, train=train, return_id=True)
+        ref = gold[f"cub_{'train' if train else 'test'}"]
+        assert len(ds) == len(ref)
+        for j, r in enumerate(ref):
+            img, target, img_id = ds[j]
+            assert (ds.data[j][1], target, img_id, list(img.size)) == (r["path"], r["target"], r["img_id"], r["size"]), (j, r)
+    for split in ("train", "test"):
+        ds = StanfordCars(mini_root, split=split)
+        ref = gold[f"cars_{split}"]
+        assert len(ds) == len(ref) and ds.classes == gold["cars_classes"]
+        for j, r in enumerate(ref):
+            img, target = ds[j]
+            assert (os.path.relpath(ds._samples[j][0], mini_root), target, list(img.size)) == (r["path"], r["target"], r["size"]), (j, r)
+    droot = os.path.join(mini_root, "dogs")
+    for train in (True, False):
+        for cropped in (False, True):
+            ds = Dogs(droot, train=train, cropped=cropped)
+            key = f"dogs_{'train' if train else 'test'}"
+            ref = gold[key + ("_cropped" if cropped else "")]
+            assert len(ds) == len(ref)
+            for j, r in enumerate(ref):
+                img, target = ds[j]
+                assert (ds._flat_breed_images[j][0], target, list(img.size)) == (r["path"], r["target"], r["size"]), (j, r)
+                if cropped:
+                    assert list(ds._flat_breed_annotations[j][1]) == r["box"]
+            if not cropped:
+                assert {str(k): v for k, v in ds.stats().items()} == gold[key + "_stats"]

@@ -85,7 +85,10 @@ def test_baseline_config_small_batch_vs_oracle(name):
     # (deit_base, D = 768: logits 3.3e-4, loss 1.7e-5, PPC 2.5e-5 / 9.0e-5, activations 2.1e-3)
     assert e["logits"] < 1e-3 and e["ce"] < 3e-5 and e["loss"] < 5e-5 and e["cov"] < 8e-5 and e["mean"] < 3e-4 and e["act"] < 6e-3, e
     # the rollout map multiplies 11 (24) bf16-derived attention maps: measured 5.3e-2 / 5.8e-2 / 2.0e-3 of its maximum
-    assert e["cls_attn"] < 0.15, e
+    assert e["cls_attn"] < 0.1, e
+    # reservation: the bf16 rollout may swap tokens whose fp32 scores sit within its error band of the k-th value; measured 7 of 162
+    # (deit_small), 3 / 4 / 3 (deit_tiny / cait_xxs24 / deit_base) -- gate at 10 % of the reserved tokens
+    assert n_diff <= 0.1 * my_idx.numel(), (n_diff, my_idx.numel())
     # deit_base: a near-tied max-pool arg-max routes one prototype's gradient to another token than in the fp32 run (the documented
     # discontinuity, test_gpu_e2e.py); every tensor then shares the same cosine, 0.983-0.986 (scripts/gpu/diag_base.py)
     floor = 0.97 if name == "deit_base" else 0.9992
@@ -138,10 +141,7 @@ def test_baseline_config_graph_replay_equals_eager(name):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu", "graph_check.py"), name, "4"], capture_output=True, text=True,
                        timeout=900, cwd=root)
     line = [l for l in r.stdout.splitlines() if l.startswith("GRAPH_CHECK ")]
-    if r.returncode < 0 and not line:
-        # the child died on a signal inside the HIP graph runtime (seen once on ROCm 7.2 when a graph was destroyed): the captured
-        # step is an opt-in path (bench.py --graph, measured slower than eager), so this is reported as a skip, not hidden as a pass
-        pytest.skip(f"hipGraph child process died with signal {-r.returncode}: {r.stderr[-300:]}")
+    # a child that dies on a signal inside the HIP graph runtime is a FAILURE of the captured-step path, not a skip
     assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(line[0][len("GRAPH_CHECK "):])
     eager, graphed = out["eager"], out["graphed"]

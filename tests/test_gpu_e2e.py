@@ -88,6 +88,10 @@ def test_micro_deit_eval_train_against_reference_fixture():
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
 
+# gradient-cosine floors of test_real_shape_train_step_vs_oracle (measured values in its comments)
+COS_ROUTED_FLOOR, COS_REST_FLOOR = 0.93, 0.97
+
+
 def _grad_agreement(m, params):
     rows = {}
     for name, p in m.named_parameters():
@@ -142,12 +146,19 @@ def test_real_shape_train_step_vs_oracle():
     loss_ref, parts = O.train_loss(out, label, cfg, with_ppc=True)
     loss_ref.backward()
     rows = _grad_agreement(m, params)
+    # a near-tied max-pool arg-max routes one prototype's gradient to another token than in the fp32 run (a discontinuity of the
+    # reference's max_pool2d, not a kernel error): it lands in that prototype's row of prototype_vectors and, through ONE token, in the
+    # add-on layer.  Those tensors are gated apart from the backbone, whose gradients sum over all tokens.
+    routed = ("prototype_vectors", "prototype_vectors_global", "add_on_layers.0.weight", "add_on_layers.0.bias")
+    cos_routed = min(c for n, (_, c) in rows.items() if n in routed)
+    cos_rest = min(c for n, (_, c) in rows.items() if n not in routed)
     report("real_shape_tiny_peaky", logits=rel_err(logits, out["logits"]), ce=rel_err(ce, parts["ce"]), cov=rel_err(cov, parts["ppc_cov"]),
-           mean=rel_err(mean, parts["ppc_mean"]), worst_cos=min(c for _, c in rows.values()))
+           mean=rel_err(mean, parts["ppc_mean"]), worst_cos=min(c for _, c in rows.values()), cos_routed=cos_routed, cos_rest=cos_rest)
     # measured (attention sharpened 6x on purpose, far peakier than any trained model): logits 1.5e-3, CE 2.4e-4, PPC 1.7e-5
     assert rel_err(logits, out["logits"]) < 4.5e-3
     assert rel_err(ce, parts["ce"]) < 8e-4 and rel_err(cov, parts["ppc_cov"]) < 6e-5 and rel_err(mean, parts["ppc_mean"]) < 6e-5
-    assert min(c for _, c in rows.values()) > 0.93, {k: v for k, v in rows.items() if v[1] <= 0.93}     # arg-max routing flips, see above
+    assert cos_routed > COS_ROUTED_FLOOR, {k: v for k, v in rows.items() if k in routed}
+    assert cos_rest > COS_REST_FLOOR, {k: v for k, v in rows.items() if k not in routed and v[1] <= COS_REST_FLOOR}
 
     # backbone backward in isolation: L = sum(w * f) on the add-on tokens (no max-pool routing) -> every parameter gradient
     # must agree with the oracle's autograd up to bf16 operand rounding accumulated over 12 layers
@@ -183,6 +194,23 @@ def test_two_rank_data_parallel_on_one_gpu():
     m = re.search(r"ranks identical after 3 steps: (\w+); loss ([0-9.]+); cos\(.*\) = ([0-9.]+)", out)
     assert m, out[-3000:]
     assert m.group(1) == "True" and float(m.group(3)) > 0.9999
+
+
+def test_single_rank_nccl_gradsync_is_bit_identical():
+    """The RCCL path on the hardware the suite runs on: one rank, backend nccl, PPF_FORCE_GRADSYNC=1 -> the chunked all-reduce really
+    runs (communication stream behind both compute streams) and three train steps equal three steps without any exchange, bit for bit
+    (scripts/gpu/nccl_single_rank_check.py, child process: the process group must not leak into the other tests)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu", "nccl_single_rank_check.py")], capture_output=True, text=True,
+                       timeout=900, cwd=root, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("NCCL_SINGLE_RANK ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(line[0][len("NCCL_SINGLE_RANK "):])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["collectives"] >= 3 * 3, out                      # >= 3 chunks per step really went through RCCL
+    assert out["params_equal"] and out["moments_equal"] and out["ema_equal"] and out["losses_equal"], out
 
 
 def test_reserved_token_compaction_matches_masked_blocks(monkeypatch):

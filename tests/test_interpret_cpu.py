@@ -80,3 +80,29 @@ def test_consistency_tables_and_cub_parts(tmp_path):
     masks = [np.eye(15)[0]] * 5
     effect, mx = I.consistency_from_tables(tables, masks, 0.8)
     assert effect == [1, 0] and mx[0] == pytest.approx(0.8)
+
+
+def test_consistency_pipeline_equals_the_reference_run():
+    """tests/golden/interp_consistency.npz holds what /root/reference/eval_interpretability.py:152-290 computed (with tools/local_parts.py's
+    tables) from mini_trees.interp_inputs() on the miniature CUB tree (tests/golden/make_golden_data.py): grid scatter, per-(class,
+    prototype) consistency flags, best part fractions and the score must be reproduced; CubParts must parse the same tables."""
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import mini_trees as M
+    z = np.load(os.path.join(here, "golden", "interp_consistency.npz"))
+    root = tempfile.mkdtemp(prefix="ppf_mini_")
+    meta = M.build_cub(root)
+    parts = I.CubParts(meta)
+    assert np.array_equal(np.array([[i, *parts.id_to_bbox[i]] for i in sorted(parts.id_to_bbox)]), z["parts_bbox"])
+    assert np.array_equal(np.array([[i, *p] for i in sorted(parts.id_to_part_loc) for p in parts.id_to_part_loc[i]]), z["parts_locs"])
+    attn, acts, targets, ids = M.interp_inputs(k=int(z["k"]), ppc=int(z["ppc"]))
+    assert np.array_equal(attn, z["attn"]) and np.array_equal(acts, z["acts"])          # the generator is deterministic
+    sizes = {int(i): M.cub_size(int(i)) for i in ids}
+    score, effects, max_parts, grid = I.consistency_from_outputs(attn, acts, targets, ids, parts, sizes, int(z["k"]), int(z["img_size"]),
+                                                                 num_classes=int(targets.max()) + 1)
+    assert np.array_equal(grid, z["grid_acts"])
+    assert effects == z["class_proto_effect"].tolist()
+    assert np.allclose(max_parts, z["class_max_part"], atol=1e-12)
+    assert score == pytest.approx(float(z["score"]), abs=1e-12) and 0.3 < score < 0.8     # a non-trivial mix of consistent / inconsistent

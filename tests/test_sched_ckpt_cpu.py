@@ -95,3 +95,21 @@ def test_parameter_order_matches_reference_state_dict():
         # module-wise order inside `features` and the relative order of the head tensors
         assert [k for k in mine if k.startswith("features.")] == [k for k in ref_keys if k.startswith("features.")], name
         assert [k for k in mine if k.startswith("add_on")] == [k for k in ref_keys if k.startswith("add_on")]
+
+
+def test_graphed_step_refuses_a_phase_it_was_not_captured_for():
+    """the captured graph bakes in the epoch >= 20 PPC branch, the coefficients and clipping; train_one_epoch must not
+    silently replay a step captured for the other phase (engine_proto.py:61-64 switches at epoch 20)."""
+    import pytest
+    from protopformer_amd.engine import GraphedTrainStep
+    early = GraphedTrainStep(model=object(), criterion=None, optimizer=None, epoch=0)
+    early.check_matches(epoch=19, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True, max_norm=None)      # same branch: fine
+    early.check_matches(epoch=3, ppc_cov_coe=0.3, ppc_mean_coe=0.9, use_ppc_loss=True, max_norm=None)       # coefficients unused before 20
+    with pytest.raises(RuntimeError, match="build a new GraphedTrainStep"):
+        early.check_matches(epoch=20, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True, max_norm=None)
+    late = GraphedTrainStep(model=object(), criterion=None, optimizer=None, epoch=20, ppc_cov_coe=0.1, ppc_mean_coe=0.5)
+    late.check_matches(epoch=35, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True, max_norm=None)
+    with pytest.raises(RuntimeError):
+        late.check_matches(epoch=35, ppc_cov_coe=0.2, ppc_mean_coe=0.5, use_ppc_loss=True, max_norm=None)
+    with pytest.raises(RuntimeError):
+        late.check_matches(epoch=35, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True, max_norm=1.0)     # captured without clipping
