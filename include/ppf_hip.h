@@ -76,6 +76,34 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
                           int trans_b, int out_f32, float alpha, int batch_outer, int batch_inner, int64_t sa_o, int64_t sa_i,
                           int64_t sb_o, int64_t sb_i, int64_t sc_o, int64_t sc_i, int kpad, ppf_stream_t stream);
 
+/* ---- full-row GEMM with row-wise fused epilogues (csrc/rowgemm.hip) ------------------------------------------------------------
+ * acc = A[M][K] . B[D][K]^T with D = the model width (192 or 384): a workgroup owns complete output rows (tiles of rows_per_tile <=
+ * 208 rows, the host passes the tokens of one sample), so what the reference does next to those rows runs in the epilogue and the
+ * GEMM output / the separate LayerNorm pass never touch HBM.  Both operands contraction-contiguous, bf16; K % 32 == 0.
+ *   ppf_rowgemm_bf16      out bf16 = acc + bias                                   input gradient of attn.proj (autograd of deit:58)
+ *   ppf_rowgemm_resid_ln  xout = res + rowscale[m / rows_per_group] * (acc + bias) (fp32, may alias res): `x = x + drop_path(attn(...))`
+ *                         / `x = x + drop_path(mlp(...))` (deit:79-80, timm DropPath); ln_out = bf16(LN(xout)), mean, rstd = the
+ *                         LayerNorm that follows (deit:79 norm2 / the next block's norm1, eps 1e-6); ln_out == NULL: residual only
+ *   ppf_rowgemm_lnbwd     dn = acc: gradient w.r.t. a LayerNorm output (input of qkv / fc1, deit:47 / timm Mlp fc1);
+ *                         dx_out = dres_in + LN'(dn; x, mean, rstd, w) (fp32, may alias dres_in; NULL = 0);
+ *                         cast_out = bf16(rowscale[m / rows_per_group] * dx_out) = the gradient entering the residual branch below
+ *                         (optional); partial[tiles][2][D] = per-tile column sums (d ln weight, d ln bias), summed in a fixed order
+ *                         by ppf_rowgemm_colsum (may run on another stream). */
+int ppf_rowgemm_supported(int D, int K, int rows_per_tile);
+int ppf_rowgemm_bf16(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* bias, void* out,
+                     ppf_stream_t stream);
+int ppf_rowgemm_resid_ln(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* bias,
+                         const float* res, float* xout, const float* rowscale, int rows_per_group, const float* ln_w, const float* ln_b,
+                         void* ln_out, float* ln_mean, float* ln_rstd, float eps, ppf_stream_t stream);
+int ppf_rowgemm_lnbwd(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* x, const float* mean,
+                      const float* rstd, const float* w, const float* dres_in, float* dx_out, void* cast_out, const float* rowscale,
+                      int rows_per_group, float* partial, size_t partial_bytes, ppf_stream_t stream);
+int ppf_rowgemm_colsum(const float* partial, int tiles, int D, float* dw, float* db, ppf_stream_t stream);
+/* Transposed bf16 copies of n weight matrices in one launch (the input-gradient products read W^T contraction-contiguous):
+ * desc (device, int64 [n][4]) = (source element offset, destination element offset, rows, cols) into src / dst; dst[c][r] = src[r][c].
+ * total_tiles = sum over the matrices of ceil(rows / 64) * ceil(cols / 64). */
+int ppf_transpose_bf16_batched(const void* src, void* dst, const void* desc_i64, int n, int total_tiles, ppf_stream_t stream);
+
 /* ---- LayerNorm (deit:67,72,238 norm1/norm2/norm, eps 1e-6) ----------------------------------------------------
  * fwd: y bf16 [rows][D] = LN(x fp32 [row_map ? row_map[r] : r][D]); saves mean / rstd per output row.
  * bwd: dx_out[src] = dres_in[src] + LN'(dy); dw/db accumulate.  Optional fused pass for the residual branch below:

@@ -314,10 +314,12 @@ def proto_activations(tokens: Tensor, protos: Tensor, activation: str = "log") -
 
 
 def ppnet_forward(sd: SD, img: Tensor, cfg: dict, train: bool = True,
-                  droppath: Optional[list] = None, force_idx: Optional[Tensor] = None) -> dict:
+                  droppath: Optional[list] = None, force_idx: Optional[Tensor] = None, force_argmax: Optional[Tensor] = None) -> dict:
     """PPNet.forward (protopformer.py:290-335) for either backbone.
 
-    cfg keys: arch ('deit'|'cait'), heads, depth, reserve_layer, reserve_k, global_coe."""
+    cfg keys: arch ('deit'|'cait'), heads, depth, reserve_layer, reserve_k, global_coe.
+    force_argmax (tests only, (B, P) int64): route the max-pool of the local branch through the given token per (sample, prototype)
+    -- e.g. the arg-max a bf16 run took -- instead of this run's own arg-max (max_pool2d is discontinuous at near-ties)."""
     feats = deit_features if cfg["arch"] == "deit" else cait_features
     x, cls_attn, idx = feats(sd, img, cfg["heads"], cfg["depth"], cfg["reserve_layer"], cfg["reserve_k"], droppath,
                              force_idx=force_idx)
@@ -328,6 +330,8 @@ def ppnet_forward(sd: SD, img: Tensor, cfg: dict, train: bool = True,
     img_f = addon_sigmoid(sd, img_tok)
     g_act, _, _ = proto_activations(cls_f, sd["prototype_vectors_global"])
     l_act, dist, act = proto_activations(img_f, sd["prototype_vectors"])
+    if force_argmax is not None:
+        l_act = act.gather(-1, force_argmax.unsqueeze(-1)).squeeze(-1)
     lg = g_act @ sd["last_layer_global.weight"].t()
     ll = l_act @ sd["last_layer.weight"].t()
     g = cfg["global_coe"]

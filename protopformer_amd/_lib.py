@@ -13,6 +13,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
 SIGS = {
     "ppf_gemm_bf16": "pppiiiiiiiiippipipppipf" "pz" "s",
     "ppf_device_info": "pppi",
+    "ppf_rowgemm_bf16": "pp" "iiiiii" "pp" "s",
+    "ppf_rowgemm_resid_ln": "pp" "iiiiii" "p" "pp" "pi" "pp" "ppp" "f" "s",
+    "ppf_rowgemm_lnbwd": "pp" "iiiiii" "pppp" "ppp" "pi" "pz" "s",
+    "ppf_rowgemm_colsum": "p" "ii" "pp" "s",
+    "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",
     "ppf_gemm_probe_read": "pppp",
     "ppf_layernorm_fwd": "ppppppp" "iif" "s",
@@ -102,6 +107,8 @@ def lib():
         _lib.ppf_sigmoid_bwd_blocks.argtypes = [ctypes.c_int]
         _lib.ppf_clip_grad_blocks.restype = ctypes.c_int
         _lib.ppf_clip_grad_blocks.argtypes = []
+        _lib.ppf_rowgemm_supported.restype = ctypes.c_int
+        _lib.ppf_rowgemm_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_stream_mark.restype = ctypes.c_int64
         _lib.ppf_stream_mark.argtypes = [ctypes.c_void_p]
         for name, spec in SIGS.items():

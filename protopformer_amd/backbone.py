@@ -86,6 +86,8 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     lane = wgrad_lane(store)
     rolled = None                                 # rollout outputs when the chain itself ran on the side stream
     roll_side = reserve_layer > 0 and os.environ.get("PPF_ROLLOUT_CHAIN_SIDE", "1") != "0"
+    pre = None                                    # (n1, mean1, rstd1) of the coming block when the previous block's fc2 GEMM produced them
+    nblk = len(feats.blocks)
     for i, blk in enumerate(feats.blocks):
         if i == reserve_layer:
             lane.join()
@@ -97,8 +99,13 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
                 rows = ops.reserved_rows_map(idx, N)
                 x = ops.gather_rows(x, rows)
                 Nc, eps_n, policy = 1 + reserve_k, N, None
+                pre = None
         M = B * Nc
-        n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        hid = blk.mlp.fc1.out_features
+        # full-row GEMMs (csrc/rowgemm.hip): the residual products also emit the LayerNorm that follows them
+        fused = ops.rowgemm_ok(D, D, Nc) and ops.rowgemm_ok(D, hid, Nc)
+        n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        pre = None
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, Nc, D, policy=policy, self_keep=True, eps_n=eps_n)
         if i < reserve_layer:
@@ -116,11 +123,23 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
                 lane.submit(lambda: ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, out=rolled),
                             (hm, thr) + rolled)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
-        x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
-        n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
-        h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
+        if fused:
+            x1, n2, mean2, rstd2 = ops.rowgemm_resid_ln(ao, store.w16(blk.attn.proj.weight), x, Nc, bias=blk.attn.proj.bias, rowscale=s1, rows_per_group=Nc,
+                                                        ln_w=blk.norm2.weight, ln_b=blk.norm2.bias, eps=LN_EPS)
+        else:
+            x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
+            n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        h = torch.empty((M, hid), dtype=torch.bfloat16, device=x.device)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
-        x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=Nc)
+        if fused:
+            # the next block's norm1 rides on this block's fc2 product, unless the token gather of the reservation comes in between
+            nxt = feats.blocks[i + 1] if (i + 1 < nblk and not (compact and i + 1 == reserve_layer)) else None
+            x2, nn1, nm1, nr1 = ops.rowgemm_resid_ln(g, store.w16(blk.mlp.fc2.weight), x1, Nc, bias=blk.mlp.fc2.bias, rowscale=s2, rows_per_group=Nc,
+                                                     ln_w=nxt.norm1.weight if nxt is not None else None, ln_b=nxt.norm1.bias if nxt is not None else None,
+                                                     eps=LN_EPS)
+            pre = (nn1, nm1, nr1) if nxt is not None else None
+        else:
+            x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=Nc)
         if save:
             layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ao=ao, rowmax=rowmax, zinv=zinv, x1=x1, n2=n2,
                                mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2, N=Nc, eps_n=eps_n,
@@ -169,7 +188,9 @@ class WgradLane:
     def __init__(self, device):
         self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
         nl = int(os.environ.get("PPF_LANES", "1"))
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(nl)] if self.enabled else []
+        # PPF_LANE_PRIORITY: HIP stream priority of the side streams (torch clamps to the device's range; larger = lower priority)
+        prio = int(os.environ.get("PPF_LANE_PRIORITY", "0"))
+        self.streams = [torch.cuda.Stream(device=device, priority=prio) for _ in range(nl)] if self.enabled else []
         self.raws = [st.cuda_stream for st in self.streams]
         self.last_read = {}         # data_ptr of a tracked buffer -> ticket of the last side-stream launch that reads it
         self.tracked = set()
@@ -296,31 +317,52 @@ def deit_backward(ppnet, store, saved, df):
         lane.before_overwrite(alt)
         return alt, cur
 
+    # Bias gradients of proj / fc2 are column sums of the bf16 branch gradient `dyb`: the LayerNorm-backward KERNEL adds them while it
+    # writes dyb (dbias_next); the fused GEMM + LayerNorm-backward (csrc/rowgemm.hip) does not, there the weight-gradient GEMM that
+    # reads dyb anyway sums its columns (COLSUM).  bias_done: the producer of the current dyb has already accumulated the bias gradient.
+    bias_done = True
     for i in range(len(layers) - 1, -1, -1):
         L, blk = layers[i], feats.blocks[i]
         Nl = L["N"]                                       # tokens per sample in this block (1+k once compacted)
+        hid = blk.mlp.fc1.out_features
+        w1t, wqt, wpt = store.w16t(blk.mlp.fc1.weight), store.w16t(blk.attn.qkv.weight), store.w16t(blk.attn.proj.weight)
+        fused = (w1t is not None and wqt is not None and wpt is not None and ops.rowgemm_ok(D, hid, Nl) and ops.rowgemm_ok(D, 3 * D, Nl)
+                 and ops.rowgemm_ok(D, D, Nl))
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
-        _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight)
+        _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias)
         dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
         _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
-        dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
         dyb, dyb_alt = next_dyb(dyb, dyb_alt)
-        lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
-                          store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl,
-                          dbias_next=store.grad_view(blk.attn.proj.bias))
+        if fused:
+            ops.rowgemm_lnbwd(dh, w1t, L["x1"], L["mean2"], L["rstd2"], blk.norm2.weight, store.grad_view(blk.norm2.weight), store.grad_view(blk.norm2.bias),
+                              Nl, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl, lane=lane, defer_reduce=True)
+        else:
+            dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
+            lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
+                              store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl,
+                              dbias_next=store.grad_view(blk.attn.proj.bias))
+        bias_done = not fused
         # attention branch: x1 = x + s1 * (attn(n1) Wp^T + bp)
-        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
-        dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
+        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, None if bias_done else blk.attn.proj.bias)
+        if fused:
+            dao = ops.rowgemm_bf16(dyb, wpt, Nl)
+        else:
+            dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
         dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True,
                             eps_n=L["eps_n"])
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
-        dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
+        dn1 = None if fused else ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
             prev = feats.blocks[i - 1]
             dyb, dyb_alt = next_dyb(dyb, dyb_alt)
-            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
-                              store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
-                              rows_per_group=Nl, dbias_next=store.grad_view(prev.mlp.fc2.bias))
+            if fused:
+                ops.rowgemm_lnbwd(dqkv, wqt, L["x"], L["mean1"], L["rstd1"], blk.norm1.weight, store.grad_view(blk.norm1.weight), store.grad_view(blk.norm1.bias),
+                                  Nl, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"], rows_per_group=Nl, lane=lane, defer_reduce=True)
+            else:
+                lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
+                                  store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
+                                  rows_per_group=Nl, dbias_next=store.grad_view(prev.mlp.fc2.bias))
+            bias_done = not fused
             if L["rows"] is not None:
                 # this block ran on the reserved rows: hand its input gradient back to the full token matrix (zeros elsewhere)
                 Mf = B * layers[i - 1]["N"]
@@ -328,8 +370,12 @@ def deit_backward(ppnet, store, saved, df):
                 dyb = lane.track(ops.scatter_rows(dyb, L["rows"], Mf))
                 dyb_alt = None
         else:
-            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
-                              store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
+            if fused:
+                ops.rowgemm_lnbwd(dqkv, wqt, L["x"], L["mean1"], L["rstd1"], blk.norm1.weight, store.grad_view(blk.norm1.weight), store.grad_view(blk.norm1.bias),
+                                  Nl, dres_in=dx, dx_out=dx, lane=lane, defer_reduce=True)
+            else:
+                lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
+                                  store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.flush()
             gs.chunk_ready(gs.block_chunk[i], also=lane.streams)
@@ -355,6 +401,10 @@ class TokensFn(torch.autograd.Function):
         store.refresh_bf16()
         feats = ppnet.features
         need_bwd = any(ctx.needs_input_grad)
+        if need_bwd and "t16_params" in ppnet._arch_fns:
+            if store._t16 is None:
+                store.register_transposed(ppnet._arch_fns["t16_params"](feats))
+            store.refresh_t16()
         saved = {} if need_bwd else None
         (layer, k), = ppnet.reserve_layer_nums
         fwd = ppnet._arch_fns
@@ -378,4 +428,9 @@ class TokensFn(torch.autograd.Function):
         return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
-DEIT_FNS = dict(embed=deit_embed, blocks=deit_blocks_fwd, backward=deit_backward)
+def deit_t16_params(feats):
+    """Weights whose input-gradient products read W^T contraction-contiguous (csrc/rowgemm.hip): fc1, qkv, proj of every block."""
+    return [w for blk in feats.blocks for w in (blk.mlp.fc1.weight, blk.attn.qkv.weight, blk.attn.proj.weight)]
+
+
+DEIT_FNS = dict(embed=deit_embed, blocks=deit_blocks_fwd, backward=deit_backward, t16_params=deit_t16_params)

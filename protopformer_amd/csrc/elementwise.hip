@@ -311,6 +311,35 @@ inline int grid_for(int64_t work, int per_block = 256) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+// dst[c][r] = src[r][c] for n bf16 matrices in one launch: desc[i] = (src element offset, dst element offset, rows, cols); a workgroup
+// transposes one 64x64 tile through LDS (coalesced 128-byte rows on both sides).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const long long* __restrict__ desc, int n) {
+    __shared__ bf16_t tile[64][66];
+    int b = blockIdx.x, i = 0;
+    for (; i < n; ++i) {
+        const int tiles = (int)((desc[4 * i + 2] + 63) / 64) * (int)((desc[4 * i + 3] + 63) / 64);
+        if (b < tiles) break;
+        b -= tiles;
+    }
+    if (i == n) return;
+    const bf16_t* s = src + desc[4 * i];
+    bf16_t* d = dst + desc[4 * i + 1];
+    const int rows = (int)desc[4 * i + 2], cols = (int)desc[4 * i + 3];
+    const int tc = (cols + 63) / 64, r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        tile[ty + 4 * k][tx] = (r < rows && c < cols) ? s[(size_t)r * cols + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ty + 4 * k, r = r0 + tx;
+        if (c < cols && r < rows) d[(size_t)c * rows + r] = tile[tx][ty + 4 * k];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -480,6 +509,13 @@ int ppf_memset_zero(void* ptr, size_t bytes, hipStream_t stream) {
 int ppf_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, hipStream_t stream) {
     PPF_CHECK_ARG(n > 0 && x && scalar_dev && out, PPF_ERR_ARG, "ppf_scale_by_scalar: bad arguments");
     hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, scalar_dev, out, n);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_transpose_bf16_batched(const void* src, void* dst, const void* desc_i64, int n, int total_tiles, hipStream_t stream) {
+    PPF_CHECK_ARG(src && dst && desc_i64 && n > 0 && total_tiles > 0, PPF_ERR_ARG, "ppf_transpose_bf16_batched: bad arguments");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(total_tiles), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, (const long long*)desc_i64, n);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -112,7 +112,7 @@ class FlatAdamW:
         st = self.store
         _lib.call("ppf_adamw_step_dev", st.params, st.grads, self.exp_avg, self.exp_avg_sq, self.ema, st.bf16, st.total, len(self.param_groups),
                   self._bounds.data_ptr(), self._hyper, self.betas[0], self.betas[1], self.eps, self.ema_decay)
-        st.bf16_fresh = True                      # the kernel re-emitted the bf16 shadow
+        st.mark_bf16_written()                    # the kernel re-emitted the bf16 shadow (its transposed copies are now stale)
 
     def step(self):
         self._check_store()

@@ -46,6 +46,36 @@ class FlatStore:
                 self._gviews[id(p)] = self.grads[o:o + n].view(p.shape)
                 p.grad = self._gviews[id(p)]
         self.bf16_fresh = False
+        self._t16 = None           # transposed bf16 shadows (register_transposed)
+
+    # ------------------------------------------------------------------ transposed bf16 shadows
+    def register_transposed(self, params):
+        """Keep W^T (bf16, [in][out]) next to the bf16 shadow of every 2-D weight in `params`: the input-gradient products
+        dx = dy W then read both operands contraction-contiguous (csrc/rowgemm.hip).  One transposing launch per refresh."""
+        params = [p for p in params if id(p) in self._views16]
+        if not params:
+            return
+        off, desc, tiles, views = 0, [], 0, {}
+        by_id = {id(p): o for _, p, o, _ in self.entries}
+        for p in params:
+            rows, cols = p.shape[0], p.numel() // p.shape[0]
+            desc.append((by_id[id(p)], off, rows, cols))
+            tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+            views[id(p)] = (off, rows, cols)
+            off += (rows * cols + ALIGN - 1) // ALIGN * ALIGN
+        buf = torch.empty(off, dtype=torch.bfloat16, device=self.device)
+        self._t16 = dict(buf=buf, desc=torch.tensor(desc, dtype=torch.int64).to(self.device), n=len(desc), tiles=tiles, fresh=False,
+                         views={k: buf[o:o + r * c].view(c, r) for k, (o, r, c) in views.items()})
+
+    def refresh_t16(self):
+        t = self._t16
+        if t is not None and not t["fresh"]:
+            ops.transpose_bf16_batched(self.bf16, t["buf"], t["desc"], t["n"], t["tiles"])
+            t["fresh"] = True
+
+    def w16t(self, p):
+        """bf16 W^T ([in][out]) of a registered weight, or None."""
+        return None if self._t16 is None else self._t16["views"].get(id(p))
 
     # ------------------------------------------------------------------ bf16 shadow
     def refresh_bf16(self, force=False):
@@ -53,12 +83,22 @@ class FlatStore:
         if force or not self.bf16_fresh:
             ops.cast_bf16(self.params, self.bf16)
             self.bf16_fresh = True
+            if self._t16 is not None:
+                self._t16["fresh"] = False
 
     def w16(self, p):
         return self._views16[id(p)]
 
+    def mark_bf16_written(self):
+        """The fused optimizer kernel has just rewritten the bf16 shadow from the new fp32 masters."""
+        self.bf16_fresh = True
+        if self._t16 is not None:
+            self._t16["fresh"] = False
+
     def invalidate(self):
         self.bf16_fresh = False
+        if self._t16 is not None:
+            self._t16["fresh"] = False
 
     # ------------------------------------------------------------------ gradients
     def grad_view(self, p):

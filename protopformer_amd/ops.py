@@ -60,6 +60,65 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
     return out
 
 
+# ------------------------------------------------------------------------------------------------ full-row GEMM + fused LayerNorm
+def rowgemm_ok(D, K, rows_per_tile):
+    """True when csrc/rowgemm.hip takes a product with output width D, contraction K and tiles of rows_per_tile rows."""
+    return os.environ.get("PPF_ROWGEMM", "1") != "0" and bool(_lib.lib().ppf_rowgemm_supported(int(D), int(K), int(rows_per_tile)))
+
+
+def rowgemm_bf16(a, b, rows_per_tile, bias=None):
+    """bf16 [M, D] = a [M, K] @ b [D, K]^T (+ bias)."""
+    _chk(a, torch.bfloat16), _chk(b, torch.bfloat16)
+    M, K = a.shape
+    D = b.shape[0]
+    out = torch.empty((M, D), dtype=torch.bfloat16, device=a.device)
+    _lib.call("ppf_rowgemm_bf16", a, b, M, D, K, K, b.shape[1], rows_per_tile, bias, out)
+    return out
+
+
+def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_per_group=1, ln_w=None, ln_b=None, eps=1e-6):
+    """x_out = res + rowscale * (a @ b^T + bias) (fp32) and, with ln_w / ln_b, n = bf16(LN(x_out)), mean, rstd of the LayerNorm that
+    follows.  Returns (x_out, n, mean, rstd) (the last three None without a LayerNorm)."""
+    _chk(a, torch.bfloat16), _chk(b, torch.bfloat16), _chk(res, torch.float32)
+    M, K = a.shape
+    D = b.shape[0]
+    xout = torch.empty((M, D), dtype=torch.float32, device=a.device)
+    n = mean = rstd = None
+    if ln_w is not None:
+        n = torch.empty((M, D), dtype=torch.bfloat16, device=a.device)
+        mean = torch.empty(M, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=a.device)
+    _lib.call("ppf_rowgemm_resid_ln", a, b, M, D, K, K, b.shape[1], rows_per_tile, bias, res, xout, rowscale, rows_per_group, ln_w, ln_b, n, mean, rstd,
+              float(eps))
+    return xout, n, mean, rstd
+
+
+def rowgemm_lnbwd(a, b, x, mean, rstd, w, dw, db, rows_per_tile, dres_in=None, dx_out=None, cast_out=None, rowscale=None, rows_per_group=1,
+                  lane=None, defer_reduce=False):
+    """dn = a @ b^T is the gradient w.r.t. the output of LN(x); dx_out = dres_in + LN'(dn) (fp32), cast_out = bf16(rowscale * dx_out);
+    dw / db (the LayerNorm's parameter gradients) += the column sums, reduced in a fixed order by a second small kernel (on `lane`,
+    the side stream, when given)."""
+    _chk(a, torch.bfloat16), _chk(b, torch.bfloat16), _chk(x, torch.float32)
+    M, K = a.shape
+    D = b.shape[0]
+    tiles = (M + rows_per_tile - 1) // rows_per_tile
+    part = torch.empty(tiles * 2 * D, dtype=torch.float32, device=a.device)
+    if dx_out is None:
+        dx_out = torch.empty((M, D), dtype=torch.float32, device=a.device)
+    _lib.call("ppf_rowgemm_lnbwd", a, b, M, D, K, K, b.shape[1], rows_per_tile, x, mean, rstd, w, dres_in, dx_out, cast_out, rowscale, rows_per_group,
+              part, part.numel() * 4)
+    red = lambda: _lib.call("ppf_rowgemm_colsum", part, tiles, D, dw, db)
+    if lane is not None:
+        lane.submit(red, (part,), defer=defer_reduce)
+    else:
+        red()
+    return dx_out
+
+
+def transpose_bf16_batched(src, dst, desc, n, total_tiles):
+    _lib.call("ppf_transpose_bf16_batched", src, dst, desc, n, total_tiles)
+
+
 def layernorm_fwd(x, w, b, eps=1e-6, row_map=None):
     """x fp32 [R, D] -> (y bf16 [rows, D], mean, rstd); rows = len(row_map) gathers source rows."""
     _chk(x, torch.float32)

@@ -70,6 +70,7 @@ class ProtoLayerFn(torch.autograd.Function):
         act_l, argmax, dist, act_full = ops.proto_fwd(f, 1, k, pl, act_kind, ppnet.epsilon, want_dist=need_bwd or want_dist, want_act=True)
         act_g, _, dist_g, _ = ops.proto_fwd(f, 0, 1, pg, act_kind, ppnet.epsilon, want_dist=need_bwd, want_act=False)
         ctx.set_materialize_grads(False)
+        ppnet._last_argmax = argmax              # (B, P) int32: the token each local prototype's max-pool selected (tests, visualisation)
         if need_bwd:
             ctx.save_for_backward(f, protos_local, protos_global)
             ctx.aux = (argmax, dist, dist_g, act_kind, ppnet)

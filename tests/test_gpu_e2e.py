@@ -88,8 +88,8 @@ def test_micro_deit_eval_train_against_reference_fixture():
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
 
-# gradient-cosine floors of test_real_shape_train_step_vs_oracle (measured values in its comments)
-COS_ROUTED_FLOOR, COS_REST_FLOOR = 0.93, 0.97
+# gradient-cosine floor of test_real_shape_train_step_vs_oracle (same reservation, same max-pool routing; measured value in its comments)
+COS_FLOOR = 0.98          # measured 0.9921
 
 
 def _grad_agreement(m, params):
@@ -141,24 +141,23 @@ def test_real_shape_train_step_vs_oracle():
     assert bool(sel[ref_attn > kth * 1.06].all()) and not bool(sel[ref_attn < kth * 0.94].any())
     n_diff = int((sel != torch.zeros_like(sel).scatter_(1, free["reserve_idx"], True)).sum()) // 2
     print(f"reserved tokens differing from the fp32 oracle: {n_diff} of {my_idx.numel()}")
-    # downstream parity with the oracle following the SAME reservation
-    out = O.ppnet_forward(params, img, cfg, train=True, force_idx=my_idx)
+    # downstream parity with the oracle following the SAME reservation and the SAME max-pool routing: a near-tied arg-max routes one
+    # prototype's gradient through another token than in the fp32 run (a discontinuity of the reference's max_pool2d, not a kernel
+    # error -- 0.94 cosine on EVERY tensor when left free), so the oracle's pooling gathers at the token the HIP run selected
+    my_arg = m._last_argmax.cpu().long()
+    out_free = O.ppnet_forward(sd, img, cfg, train=True, force_idx=my_idx)
+    n_flip = int((out_free["total_proto_act"].flatten(2).argmax(-1) != my_arg).sum())
+    out = O.ppnet_forward(params, img, cfg, train=True, force_idx=my_idx, force_argmax=my_arg)
     loss_ref, parts = O.train_loss(out, label, cfg, with_ppc=True)
     loss_ref.backward()
     rows = _grad_agreement(m, params)
-    # a near-tied max-pool arg-max routes one prototype's gradient to another token than in the fp32 run (a discontinuity of the
-    # reference's max_pool2d, not a kernel error): it lands in that prototype's row of prototype_vectors and, through ONE token, in the
-    # add-on layer.  Those tensors are gated apart from the backbone, whose gradients sum over all tokens.
-    routed = ("prototype_vectors", "prototype_vectors_global", "add_on_layers.0.weight", "add_on_layers.0.bias")
-    cos_routed = min(c for n, (_, c) in rows.items() if n in routed)
-    cos_rest = min(c for n, (_, c) in rows.items() if n not in routed)
     report("real_shape_tiny_peaky", logits=rel_err(logits, out["logits"]), ce=rel_err(ce, parts["ce"]), cov=rel_err(cov, parts["ppc_cov"]),
-           mean=rel_err(mean, parts["ppc_mean"]), worst_cos=min(c for _, c in rows.values()), cos_routed=cos_routed, cos_rest=cos_rest)
+           mean=rel_err(mean, parts["ppc_mean"]), worst_cos=min(c for _, c in rows.values()), argmax_flips=n_flip, argmax_total=my_arg.numel())
     # measured (attention sharpened 6x on purpose, far peakier than any trained model): logits 1.5e-3, CE 2.4e-4, PPC 1.7e-5
     assert rel_err(logits, out["logits"]) < 4.5e-3
     assert rel_err(ce, parts["ce"]) < 8e-4 and rel_err(cov, parts["ppc_cov"]) < 6e-5 and rel_err(mean, parts["ppc_mean"]) < 6e-5
-    assert cos_routed > COS_ROUTED_FLOOR, {k: v for k, v in rows.items() if k in routed}
-    assert cos_rest > COS_REST_FLOOR, {k: v for k, v in rows.items() if k not in routed and v[1] <= COS_REST_FLOOR}
+    assert n_flip <= 0.06 * my_arg.numel(), (n_flip, my_arg.numel())           # the routing itself agrees on all but near-ties (measured 22 of 800)
+    assert min(c for _, c in rows.values()) > COS_FLOOR, {k: v for k, v in rows.items() if v[1] <= COS_FLOOR}
 
     # backbone backward in isolation: L = sum(w * f) on the add-on tokens (no max-pool routing) -> every parameter gradient
     # must agree with the oracle's autograd up to bf16 operand rounding accumulated over 12 layers
