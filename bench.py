@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per step instead of enqueueing every kernel from the host")
+    ap.add_argument("--eager", action="store_true", help="run the Python orchestration every step instead of replaying the recorded command list")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the multi-rank launch + all-reduce plumbing (no GPU, no measurement)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
     args = ap.parse_args()
@@ -277,7 +278,7 @@ def main():
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
 
     from protopformer_amd import _lib, ops
-    from protopformer_amd.engine import GraphedTrainStep, train_one_step
+    from protopformer_amd.engine import GraphedTrainStep, ReplayedTrainStep, train_one_step
     # the reference seeds every rank with seed + rank (main.py:254) and relies on DDP's rank-0 broadcast (main.py:370) to make the
     # replicas identical; same here: make_grad_sync() broadcasts rank 0's parameters / optimizer state
     model, opt, crit, sync = build(cfg, device, seed=1028 + rank)
@@ -286,13 +287,21 @@ def main():
     label = torch.randint(0, cfg["C"], (batch,), device=device, generator=g)
 
     graphed = None
-    graph_note = "kernels enqueued from the host each step, two HIP streams"
+    graph_note = "kernels enqueued from the host each step by the Python orchestration, two HIP streams"
     if args.graph:
         graphed = GraphedTrainStep(model, crit, opt, epoch=20, grad_sync=sync, warmup=2, adopt_inputs=True)     # the batch is resident
+    replayed = None
+    if not args.graph and not args.eager:
+        # default: two eager steps, then one recorded step; every later step replays the recorded launches (same kernels, arguments,
+        # streams and dependencies, enqueued by one ctypes call each: engine.ReplayedTrainStep) -- the full step is still executed
+        replayed = ReplayedTrainStep(model, crit, opt, epoch=20, grad_sync=sync, warmup=2, adopt_inputs=True)
+        graph_note = "kernels enqueued from the host each step from a recorded command list (engine.ReplayedTrainStep), two HIP streams"
 
     def step():
         if graphed is not None:
             return graphed(img, label)
+        if replayed is not None:
+            return replayed(img, label)
         return train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
 
     done = 0

@@ -248,6 +248,9 @@ int ppf_reserved_rows_map(const int* idx, int* rows, int B, int k, int N, ppf_st
 int ppf_gather_rows(const void* src, const int* rows, void* dst, int nrows, int row_bytes, ppf_stream_t stream);
 int ppf_scatter_rows(const void* src, const int* rows, void* dst, int nrows_src, int nrows_dst, int row_bytes, ppf_stream_t stream);
 int ppf_memset_zero(void* ptr, size_t bytes, ppf_stream_t stream);
+/* strided sub-matrix copy (bytes): dst[r][0..width) = src[r][0..width), rows rows, independent row pitches (torch.cat / slicing of the
+ * class-attention stage, cait:314-316, kept on the library's launch path) */
+int ppf_copy_2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width, int64_t rows, ppf_stream_t stream);
 /* input pipeline finisher (tools/datasets.py:280-336: ToTensor + Normalize; timm RandomErasing 'pixel'): uint8 [B][H][W][3] frames
  * -> fp32 [B][3][H][W] = (x/255 - mean)/std; rects [B][4] = (y, x, h, w) erase rectangles filled with N(0,1) noise (h == 0: none;
  * rects == NULL: no erasing); mean3 / std3 are HOST pointers; state_u64 (device, optional) = step counter mixed into the noise key. */

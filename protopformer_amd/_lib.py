@@ -67,6 +67,7 @@ SIGS = {
     "ppf_gather_rows": "ppp" "ii" "s",
     "ppf_scatter_rows": "ppp" "iii" "s",
     "ppf_memset_zero": "pz" "s",
+    "ppf_copy_2d": "pl" "pl" "ll" "s",
     "ppf_image_finish_u8": "pp" "iii" "ppp" "Lp" "s",
     "ppf_scale_by_scalar": "ppp" "l" "s",
     "ppf_stream_wait_stream": "pp",
@@ -170,3 +171,89 @@ def call(name, *args):
     rc = fn(*a)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {_lib.ppf_last_error().decode()}")
+    if _rec is not None and not _rec.suspended:
+        _rec.add_call(name, fn, a, args)
+
+
+# ------------------------------------------------------------------------------------------------ recorded command lists
+# One train step is ~300-800 launches; enqueueing them from Python costs ~20 us each (allocation, shape logic, autograd), which makes
+# the small configurations host-bound (HIP graphs do not help on ROCm 7.2: hipGraphLaunch re-enqueues every node from the host at
+# the same cost, profiles/r2_graph_timeline.txt).  A Recorder keeps, for ONE eagerly executed step, every library call with its
+# converted arguments (raw pointers, sizes, streams) and keeps the tensors alive, so their addresses stay valid; replay() then walks
+# the list: one pre-bound ctypes call (~2-3 us) per launch, no Python orchestration, no allocation, no autograd.  What cannot be
+# frozen runs as a LIVE Python callable in its place in the list (optimizer scalars, the RCCL collectives of the gradient exchange).
+class Recorder:
+    CALL, MARK, WAIT, LIVE = 0, 1, 2, 3
+
+    def __init__(self):
+        self.cmds, self.keep, self.tickets, self.nslots, self.suspended = [], [], {}, 0, 0
+
+    def add_call(self, name, fn, a, args):
+        if name == "ppf_stream_wait_mark":
+            slot = self.tickets.get(a[1])
+            if slot is not None:              # (a ticket taken before the recording started guards work that is long complete)
+                self.cmds.append((Recorder.WAIT, fn, a[0], slot))
+            return
+        self.cmds.append((Recorder.CALL, fn, tuple(a), name))
+        self.keep.append(args)                # the tensors behind the recorded pointers stay allocated
+
+
+_rec = None
+
+
+def start_recording():
+    global _rec
+    if _rec is not None:
+        raise RuntimeError("a recording is already in progress")
+    _rec = Recorder()
+    return _rec
+
+
+def stop_recording():
+    global _rec
+    r, _rec = _rec, None
+    return r
+
+
+def stream_mark(raw):
+    """Ticket for 'everything enqueued on `raw` so far' (ppf_stream_mark); recorded symbolically: a replay takes a fresh ticket."""
+    t = lib().ppf_stream_mark(raw)
+    if t < 0:
+        raise RuntimeError(_lib.ppf_last_error().decode())
+    if _rec is not None and not _rec.suspended:
+        _rec.tickets[t] = _rec.nslots
+        _rec.cmds.append((Recorder.MARK, raw, _rec.nslots))
+        _rec.nslots += 1
+    return t
+
+
+def run_live(fn):
+    """Run fn() now; inside a recording it also becomes a LIVE entry of the command list (executed again by every replay, at this
+    position): host-side state that changes from step to step (optimizer scalars) and calls outside the library (collectives)."""
+    if _rec is None or _rec.suspended:
+        return fn()
+    _rec.suspended += 1
+    try:
+        out = fn()
+    finally:
+        _rec.suspended -= 1
+    _rec.cmds.append((Recorder.LIVE, fn))
+    return out
+
+
+def replay(rec):
+    """Enqueue a recorded step again: same kernels, same arguments, same streams and cross-stream dependencies."""
+    slots = [0] * rec.nslots
+    mark = _lib.ppf_stream_mark
+    for c in rec.cmds:
+        k = c[0]
+        if k == 0:
+            rc = c[1](*c[2])
+            if rc != 0:
+                raise RuntimeError(f"{c[3]} failed in replay (rc={rc}): {_lib.ppf_last_error().decode()}")
+        elif k == 1:
+            slots[c[2]] = mark(c[1])
+        elif k == 2:
+            c[1](c[2], slots[c[3]])
+        else:
+            c[1]()

@@ -15,6 +15,9 @@ from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, 
 
 LN_EPS = 1e-6
 _KEEP_CACHE = {}
+# Measurement only (results are WRONG): PPF_KNOCKOUT=wgrad,headmean,thr,attnbwd,... skips those launches so that scripts/gpu/ab_step.py can
+# price what each family costs INSIDE the two-stream step (stand-alone kernel times do not add up there).
+_KO = set(filter(None, os.environ.get("PPF_KNOCKOUT", "").replace("+", ",").split(",")))
 
 
 def droppath_scales(rates, B, device, training):
@@ -112,8 +115,9 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
             # only the rollout at `reserve_layer` consumes the head-mean maps: recompute them on the side stream, under the
             # rest of this block
             def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i):
-                ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
-                if side_thr:
+                if "headmean" not in _KO:
+                    ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
+                if side_thr and "thr" not in _KO:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
             lane.submit(side, (qkv, rowmax, zinv, hm, thr))
             if roll_side and i == reserve_layer - 1:
@@ -215,21 +219,17 @@ class WgradLane:
     def flush(self, tag=None):
         if not self.pending:
             return
-        L = _lib.lib()
         # lane 0 carries the weight gradients; the long prototype-gradient kernels at the start of backward (tag "PROTO") get a lane
         # of their own when there is one, so that the first weight gradients do not queue behind them
         raw = self.raws[1] if (tag == "PROTO" and len(self.raws) > 1) else self.raws[0]
-        if L.ppf_stream_wait_stream(raw, _lib.stream_ptr()):
-            raise RuntimeError(L.ppf_last_error().decode())
+        _lib.call("ppf_stream_wait_stream", raw, _lib.stream_ptr())
         _lib.push_stream(raw)
         try:
             for fn, reads in self.pending:
                 fn()
                 ptrs = [t.data_ptr() for t in reads if t.data_ptr() in self.tracked]
                 if ptrs:
-                    ticket = L.ppf_stream_mark(raw)
-                    if ticket < 0:
-                        raise RuntimeError(L.ppf_last_error().decode())
+                    ticket = _lib.stream_mark(raw)
                     for q in ptrs:
                         self.last_read[q] = ticket
         finally:
@@ -267,6 +267,8 @@ def wgrad_lane(store):
 def _wgrad(store, dy16, x16, weight, bias=None):
     """dW[N,K] += dy^T x (deterministic split-K into the flat grad), optional fused bias grad (column sums of dy); queued on
     the weight-gradient lane."""
+    if "wgrad" in _KO:
+        return
     gw = store.grad_view(weight)
     gb = store.grad_view(bias) if bias is not None else None
     wgrad_lane(store).submit(lambda: ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
@@ -301,7 +303,7 @@ def deit_backward(ppnet, store, saved, df):
     gs = getattr(ppnet, "_grad_sync", None)           # data-parallel: all-reduce chunks as their layers complete
     if gs is not None:
         lane.flush()
-        gs.chunk_ready(gs.tail_chunk, also=lane.streams)
+        _lib.run_live(lambda: gs.chunk_ready(gs.tail_chunk, also=lane.streams))
     # The bf16 branch gradient alternates between two buffers: the LayerNorm backward that produces the next one does not have to
     # wait for the side stream's weight-gradient GEMM that still reads the current one (the main stream would otherwise be tied to
     # the progress of the side stream twice per block).  PPF_DYB_PINGPONG=0: one buffer, overwritten in place.
@@ -348,8 +350,8 @@ def deit_backward(ppnet, store, saved, df):
             dao = ops.rowgemm_bf16(dyb, wpt, Nl)
         else:
             dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
-        dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True,
-                            eps_n=L["eps_n"])
+        dqkv = (torch.empty_like(L["qkv"]) if "attnbwd" in _KO else
+                ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True, eps_n=L["eps_n"]))
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
         dn1 = None if fused else ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
@@ -378,7 +380,7 @@ def deit_backward(ppnet, store, saved, df):
                                   store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.flush()
-            gs.chunk_ready(gs.block_chunk[i], also=lane.streams)
+            _lib.run_live(lambda c=gs.block_chunk[i]: gs.chunk_ready(c, also=lane.streams))
     # token assembly + patch embedding
     pe = feats.patch_embed
     Np = pe.num_patches
@@ -388,7 +390,7 @@ def deit_backward(ppnet, store, saved, df):
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
         lane.flush()
-        gs.chunk_ready(gs.head_chunk, also=lane.streams)
+        _lib.run_live(lambda: gs.chunk_ready(gs.head_chunk, also=lane.streams))
     lane.join()
 
 

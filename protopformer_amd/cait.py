@@ -11,7 +11,7 @@ import functools
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .backbone import LN_EPS, _dp, _wgrad, head_tokens_fwd, wgrad_lane
 from .deit import _Mlp, _PatchEmbed, _init_vit
 from .ops import EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID
@@ -154,16 +154,19 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         x = x2
     # ---- class-attention stage: only the cls token changes
     N1 = N + 1
-    cls = feats.cls_token.detach().reshape(1, D).expand(B, D).contiguous()
+    # (every sub-matrix copy of this stage goes through the library -- ops.gather_rows / copy_2d / cat_rows -- not through ATen: a
+    # recorded step, engine.ReplayedTrainStep, replays library calls only)
+    cls = ops.gather_rows(feats.cls_token.detach().reshape(1, D), _zero_rows(B, x.device))        # cls_token broadcast to [B, D]
     xt = x.reshape(B, N, D)
     policy = cls_attn = idx = None
-    ca_layers, rowmeans = [], []
+    ca_layers = []
+    rowmeans = torch.empty((len(feats.blocks_token_only), B, N1), dtype=torch.float32, device=x.device)
     for j, blk in enumerate(feats.blocks_token_only):
         if j == reserve_layer:
-            init_rows = torch.stack(rowmeans).contiguous()                       # class-attention rows produced so far (cait:249-251)
+            init_rows = rowmeans[:j]                                              # class-attention rows produced so far (cait:249-251)
             lane.join()
             cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows, thr=thr)
-        u = torch.cat([cls.reshape(B, 1, D), xt], dim=1).reshape(B * N1, D)
+        u = ops.cat_rows(cls, xt).reshape(B * N1, D)
         n, mean1, rstd1 = ops.layernorm_fwd(u, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         kk = ops.gemm(n, store.w16(blk.attn.k.weight), epi=EPI_BF16, bias=blk.attn.k.bias)
         vv = ops.gemm(n, store.w16(blk.attn.v.weight), epi=EPI_BF16, bias=blk.attn.v.bias)
@@ -171,8 +174,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         qq = torch.empty((B, D), dtype=torch.bfloat16, device=x.device)
         ops._lib.call("ppf_gemm_bf16", n, store.w16(blk.attn.q.weight), qq, B, D, D, N1 * D, D, D, 0, 0, EPI_BF16, blk.attn.q.bias, None, 0,
                       None, 1, None, None, None, 0, None, 1.0, None, 0)
-        out, attn, zinv, rowmean = ops.class_attn_fwd(qq, kk, vv, policy, B, H, N1, D)
-        rowmeans.append(rowmean)
+        out, attn, zinv, _ = ops.class_attn_fwd(qq, kk, vv, policy, B, H, N1, D, rowmean=rowmeans[j])
         raw1 = torch.empty((B, D), dtype=torch.bfloat16, device=x.device) if save else None
         cls1 = ops.gemm(out, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=cls, colscale=blk.gamma_1, aux_out=raw1)
         n2, mean2, rstd2 = ops.layernorm_fwd(cls1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
@@ -185,8 +187,20 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
                                   n2=n2, mean2=mean2, rstd2=rstd2, h=h, g=g, raw1=raw1, raw2=raw2, policy=policy))
         cls = cls2
     lane.join()
-    u_out = torch.cat([cls.reshape(B, 1, D), xt], dim=1)
+    u_out = ops.cat_rows(cls, xt)
     return u_out, cls_attn, idx, dict(sa=layers, ca=ca_layers)
+
+
+_ZERO_ROWS = {}
+
+
+def _zero_rows(B, device):
+    """int32 [B] of zeros: the row map that broadcasts one source row to B rows (ops.gather_rows); cached per batch size."""
+    key = (B, str(device))
+    t = _ZERO_ROWS.get(key)
+    if t is None:
+        t = _ZERO_ROWS[key] = torch.zeros(B, dtype=torch.int32, device=device)
+    return t
 
 
 # ------------------------------------------------------------------------------------------------ backward
@@ -245,7 +259,8 @@ def cait_backward(ppnet, store, saved, df):
     lnb(dnf, u_last.reshape(B * N1, D), feats.norm.weight, head["meanf"], head["rstdf"], gv(feats.norm.weight),
                       gv(feats.norm.bias), dx_out=du, row_map=head["row_map"])
     du3 = du.reshape(B, N1, D)
-    dcls = du3[:, 0].contiguous()
+    du2 = du.reshape(B, N1 * D)
+    dcls = ops.copy_2d(torch.empty((B, D), dtype=torch.float32, device=dev), du2[:, :D])
     # ---- class-attention blocks (reverse)
     for j in range(len(ca) - 1, -1, -1):
         L, blk = ca[j], feats.blocks_token_only[j]
@@ -270,14 +285,14 @@ def cait_backward(ppnet, store, saved, df):
         dnv = ops.gemm(dv, store.w16(blk.attn.v.weight), trans_b=True, epi=EPI_F32)
         dnq = ops.gemm(dq, store.w16(blk.attn.q.weight), trans_b=True, epi=EPI_F32)
         dn16 = ops.merge3_cast(dnk, dnv, dnq, N1)
-        du3[:, 0].copy_(dcls)                               # gradient reaching this block's cls input through the residual path
+        ops.copy_2d(du2[:, :D], dcls)                      # gradient reaching this block's cls input through the residual path
         lnb(dn16, L["u"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=du, dx_out=du)
-        dcls = du3[:, 0].contiguous()
+        dcls = ops.copy_2d(torch.empty((B, D), dtype=torch.float32, device=dev), du2[:, :D])
     # cls_token parameter: sum over the batch of the cls gradient (column sums via the scale/cast pass)
     scratch = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
     lnb(None, None, None, None, None, None, None, dres_in=dcls, cast_out=scratch, dbias_next=gv(feats.cls_token).reshape(D))
     # ---- talking-heads blocks (reverse)
-    dx = du3[:, 1:].contiguous().reshape(M, D)
+    dx = ops.copy_2d(torch.empty((B, N * D), dtype=torch.float32, device=dev), du2[:, D:]).reshape(M, D)
     dyb = lane.track(torch.empty((M, D), dtype=torch.bfloat16, device=dev))
     last = feats.blocks[-1]
     lnb(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
@@ -305,15 +320,15 @@ def cait_backward(ppnet, store, saved, df):
             lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.flush()
-            gs.chunk_ready(gs.block_chunk[i], also=lane.streams)
+            _lib.run_live(lambda c=gs.block_chunk[i]: gs.chunk_ready(c, also=lane.streams))
     pe = feats.patch_embed
     dtok = ops.assemble_tokens_bwd(dx, gv(feats.pos_embed).reshape(N, D), None, B, N, D, 0)
     _wgrad(store, dtok, saved["cols"], pe.proj.weight, pe.proj.bias)
     if gs is not None:
         lane.flush()
-        gs.chunk_ready(gs.head_chunk, also=lane.streams)
+        _lib.run_live(lambda: gs.chunk_ready(gs.head_chunk, also=lane.streams))
         lane.flush()
-        gs.chunk_ready(gs.tail_chunk, also=lane.streams)
+        _lib.run_live(lambda: gs.chunk_ready(gs.tail_chunk, also=lane.streams))
     lane.join()
 
 

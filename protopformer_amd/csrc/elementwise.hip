@@ -520,4 +520,14 @@ int ppf_transpose_bf16_batched(const void* src, void* dst, const void* desc_i64,
     return 0;
 }
 
+// dst[r][0 .. width) = src[r][0 .. width) for `rows` rows with independent row pitches (bytes): the strided sub-matrix copies of the CaiT
+// class-attention stage (torch.cat of the cls row with the patch rows, cait:314-316; the cls row of a gradient), on the library's
+// own launch path so that a recorded step (engine.ReplayedTrainStep) contains them.
+int ppf_copy_2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width, int64_t rows, hipStream_t stream) {
+    PPF_CHECK_ARG(dst && src && width > 0 && rows > 0 && dst_pitch >= width && src_pitch >= width, PPF_ERR_ARG, "ppf_copy_2d: bad arguments");
+    hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)width, (size_t)rows, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) { ppf_set_error("ppf_copy_2d: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 }  // extern "C"

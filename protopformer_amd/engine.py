@@ -116,8 +116,14 @@ class FlatAdamW:
 
     def step(self):
         self._check_store()
-        self.refresh_hyper()
+        clip = self._clip_issued
+        # the step-dependent scalars are read on the host NOW: inside a recorded step (engine.ReplayedTrainStep) this is a live entry
+        _lib.run_live(lambda: self._live_refresh(clip))
         self.launch_update()
+
+    def _live_refresh(self, clip_issued):
+        self._clip_issued = clip_issued           # a replay re-runs the recorded clip kernel in front of this point
+        self.refresh_hyper()
 
     # ------------------------------------------------------------------ checkpoint format: torch.optim.AdamW's
     def state_dict(self):
@@ -373,7 +379,7 @@ def _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_
     loss.backward(gradient=ops.const_scalar(loss.device, 1.0))    # cached seed: no ones_like fill, and the loss Fns skip their scaling
     model._grad_sync = None
     if grad_sync is not None:
-        optimizer.grad_scale = grad_sync.finish()
+        _lib.run_live(lambda: setattr(optimizer, "grad_scale", grad_sync.finish()))
     if max_norm is not None:                                      # loss_scaler(..., clip_grad=max_norm) (engine_proto.py:74-76)
         optimizer.clip_grad_norm(max_norm)
     return loss, cov, mean
@@ -455,10 +461,44 @@ class GraphedTrainStep:
         return self.out
 
 
+class ReplayedTrainStep(GraphedTrainStep):
+    """The same step as a recorded COMMAND LIST (protopformer_amd/_lib.py Recorder): after `warmup` eager calls, one step is executed
+    eagerly while every library call (kernel launch, stream dependency) is recorded with its raw arguments; later calls replay the
+    list -- one pre-bound ctypes call per launch instead of the Python orchestration, allocation and autograd of the eager step
+    (~20 us -> ~3 us of host time per launch).  Unlike a HIP graph the replay enqueues ordinary launches on the two ordinary streams,
+    so the overlap of the eager step is kept.  The recorded step's tensors become static buffers (inputs are copied in, the returned
+    loss tensors are overwritten by the next call); optimizer scalars and the gradient collectives run live inside the list."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.rec = None
+
+    def __call__(self, samples, targets):
+        opt = self.optimizer
+        opt._check_store()
+        self.calls += 1
+        if self.rec is None:
+            if self.calls <= self.warmup:
+                return train_one_step(self.model, self.criterion, samples, targets, opt, **self.kw)
+            self.static_in = (samples, targets) if self.adopt_inputs else (samples.clone(), targets.clone())
+            _lib.start_recording()
+            try:
+                self.out = train_one_step(self.model, self.criterion, self.static_in[0], self.static_in[1], opt, **self.kw)
+            finally:
+                self.rec = _lib.stop_recording()
+            return self.out
+        if samples.data_ptr() != self.static_in[0].data_ptr():
+            self.static_in[0].copy_(samples, non_blocking=True)
+        if targets.data_ptr() != self.static_in[1].data_ptr():
+            self.static_in[1].copy_(targets, non_blocking=True)
+        _lib.replay(self.rec)
+        return self.out
+
+
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, args=None, grad_sync=None, log_every=30, logger=print,
                     max_norm=None, step_fn=None):
     """Epoch loop with the reference's signature shape (engine_proto.py:24-113); data_loader yields (samples, targets).
-    step_fn: a GraphedTrainStep (replayed graph) instead of the eager train_one_step."""
+    step_fn: a ReplayedTrainStep (recorded command list) or GraphedTrainStep (captured HIP graph) instead of the eager train_one_step."""
     model.train(True)
     use_ppc = True if args is None else bool(getattr(args, "use_ppc_loss", True))
     cov_coe = 0.1 if args is None else getattr(args, "ppc_cov_coe", 0.1)

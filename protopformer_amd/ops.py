@@ -373,6 +373,25 @@ def zero_(t):
     return t
 
 
+def copy_2d(dst, src):
+    """dst[...] = src[...] for 2-D views (rows, cols) whose rows are contiguous: strided sub-matrix copy on the library's launch path
+    (recordable; replaces torch.cat / slice.contiguous() / slice.copy_ in the CaiT class-attention stage)."""
+    assert dst.dim() == 2 and src.dim() == 2 and dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1 and dst.dtype == src.dtype
+    es = dst.element_size()
+    _lib.call("ppf_copy_2d", dst, dst.stride(0) * es, src, src.stride(0) * es, dst.shape[1] * es, dst.shape[0])
+    return dst
+
+
+def cat_rows(first, rest):
+    """torch.cat([first [B,1,D], rest [B,N,D]], dim=1) -> [B, 1+N, D] with two strided copies."""
+    B, N, D = rest.shape
+    out = torch.empty((B, N + 1, D), dtype=rest.dtype, device=rest.device)
+    o2 = out.reshape(B, (N + 1) * D)
+    copy_2d(o2[:, :D], first.reshape(B, D))
+    copy_2d(o2[:, D:], rest.reshape(B, N * D))
+    return out
+
+
 def reserved_rows_map(idx, N):
     """Flat source rows [B*(1+k)] int32 of [cls, 1+idx...] in the [B*N] token matrix."""
     B, k = idx.shape
@@ -454,11 +473,12 @@ def th_dwl(qkv, ds_prime, dwl, B, H, N, D):
     _lib.call("ppf_th_dwl", qkv, ds_prime, dwl, B, H, N, D, ds_prime.shape[-1])
 
 
-def class_attn_fwd(q, k, v, policy, B, H, N1, D):
+def class_attn_fwd(q, k, v, policy, B, H, N1, D, rowmean=None):
     dev = q.device
     attn = torch.empty((B, H, N1), dtype=torch.float32, device=dev)
     zinv = torch.empty((B, H), dtype=torch.float32, device=dev)
-    rowmean = torch.empty((B, N1), dtype=torch.float32, device=dev)
+    if rowmean is None:
+        rowmean = torch.empty((B, N1), dtype=torch.float32, device=dev)
     out = torch.empty((B, D), dtype=torch.bfloat16, device=dev)
     _lib.call("ppf_class_attn_fwd", q, k, v, policy, attn, zinv, rowmean, out, B, H, N1, D)
     return out, attn, zinv, rowmean
