@@ -17,6 +17,17 @@ LN_EPS = 1e-6
 _KEEP_CACHE = {}
 # Measurement only (results are WRONG): PPF_KNOCKOUT=wgrad,headmean,thr,attnbwd,... skips those launches so that scripts/gpu/ab_step.py can
 # price what each family costs INSIDE the two-stream step (stand-alone kernel times do not add up there).
+# PPF_ROWGEMM_FWD / PPF_ROWGEMM_BWD = 0 / 1: keep / use the full-row GEMMs with fused LayerNorm in the forward / backward pass (A/B).
+# Backward default "auto" (measured, profiles/r3_rowgemm.txt section 7): in the backward pass the full-row kernels own whole CUs while the
+# weight-gradient GEMMs of the side stream want to share them -- a win where the step is launch-bound (deit_tiny batch 128: +7.5 %),
+# neutral in throughput at deit_small batch 256 where it stretches the weight-gradient kernels from 100 to 137 us; so: small problems only.
+_ROW_FWD = os.environ.get("PPF_ROWGEMM_FWD", "1") != "0"
+_ROW_BWD = os.environ.get("PPF_ROWGEMM_BWD", "auto")
+_ROW_BWD_MAX_ELEMS = 12_000_000          # rows x width of the residual stream up to which the backward pass uses them
+
+
+def _row_bwd(M, D):
+    return _ROW_BWD == "1" or (_ROW_BWD == "auto" and M * D <= _ROW_BWD_MAX_ELEMS)
 _KO = set(filter(None, os.environ.get("PPF_KNOCKOUT", "").replace("+", ",").split(",")))
 
 
@@ -106,7 +117,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         M = B * Nc
         hid = blk.mlp.fc1.out_features
         # full-row GEMMs (csrc/rowgemm.hip): the residual products also emit the LayerNorm that follows them
-        fused = ops.rowgemm_ok(D, D, Nc) and ops.rowgemm_ok(D, hid, Nc)
+        fused = _ROW_FWD and ops.rowgemm_ok(D, D, Nc) and ops.rowgemm_ok(D, hid, Nc)
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         pre = None
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
@@ -328,7 +339,7 @@ def deit_backward(ppnet, store, saved, df):
         Nl = L["N"]                                       # tokens per sample in this block (1+k once compacted)
         hid = blk.mlp.fc1.out_features
         w1t, wqt, wpt = store.w16t(blk.mlp.fc1.weight), store.w16t(blk.attn.qkv.weight), store.w16t(blk.attn.proj.weight)
-        fused = (w1t is not None and wqt is not None and wpt is not None and ops.rowgemm_ok(D, hid, Nl) and ops.rowgemm_ok(D, 3 * D, Nl)
+        fused = (_row_bwd(B * Nl, D) and w1t is not None and wqt is not None and wpt is not None and ops.rowgemm_ok(D, hid, Nl) and ops.rowgemm_ok(D, 3 * D, Nl)
                  and ops.rowgemm_ok(D, D, Nl))
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
         _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias)

@@ -106,3 +106,4 @@ def test_transposed_weight_shadow():
     torch.cuda.synchronize()
     for so, do, r, c in desc:
         assert torch.equal(dst[do:do + r * c].view(c, r), src[so:so + r * c].view(r, c).t())
+
