@@ -7,7 +7,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 import torch.distributed as dist
 import bench
-from protopformer_amd.engine import FlatAdamW, make_grad_sync, train_one_step
+from protopformer_amd.engine import FlatAdamW, ReplayedTrainStep, make_grad_sync, train_one_step
 from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -36,6 +36,10 @@ assert bool(torch.equal(lo, hi)), "rank-0 broadcast did not make the replicas id
 assert bool(torch.equal(opt.ema, p0)), "EMA copy must follow the broadcast parameters"
 for it in range(3):
     loss, cov, mean = train_one_step(m, crit, img, lab, opt, epoch=20, grad_sync=sync)
+# three more steps through the recorded command list (bench.py's default execution): eager, recorded, replayed
+rstep = ReplayedTrainStep(m, crit, opt, epoch=20, grad_sync=sync, warmup=1)
+for it in range(3):
+    loss, cov, mean = rstep(img, lab)
 torch.cuda.synchronize()
 p = m.flat_store().params
 lo, hi = p.clone(), p.clone()

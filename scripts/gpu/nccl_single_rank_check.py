@@ -15,14 +15,14 @@ import torch
 import torch.distributed as dist
 
 from protopformer_amd import backbone
-from protopformer_amd.engine import FlatAdamW, make_grad_sync, train_one_step
+from protopformer_amd.engine import FlatAdamW, ReplayedTrainStep, make_grad_sync, train_one_step
 from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
 
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 
 
-def run(sync_on, steps=3):
+def run(sync_on, steps=3, replay=False):
     backbone._KEEP_CACHE.clear()                       # DropPath stream restarts: identical draws in both runs
     torch.manual_seed(7)
     m = construct_PPNet("deit_tiny_patch16_224", pretrained=False, img_size=224, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[11],
@@ -35,8 +35,9 @@ def run(sync_on, steps=3):
     lab = torch.randint(0, 20, (8,), device=dev, generator=g)
     crit = CrossEntropyLoss()
     losses = []
+    step = ReplayedTrainStep(m, crit, opt, epoch=20, grad_sync=sync, warmup=1) if replay else None      # eager, recorded, then replayed steps
     for _ in range(steps):
-        loss, _, _ = train_one_step(m, crit, img, lab, opt, epoch=20, grad_sync=sync)
+        loss, _, _ = step(img, lab) if replay else train_one_step(m, crit, img, lab, opt, epoch=20, grad_sync=sync)
         losses.append(float(loss))
     torch.cuda.synchronize()
     launched = 0 if sync is None else sync.launched
@@ -46,7 +47,11 @@ def run(sync_on, steps=3):
 p0, m0, e0, l0, _ = run(False)
 dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1, device_id=dev)
 p1, m1, e1, l1, launched = run(True)
+# the bench's default execution: the recorded command list, with the collectives as live entries of the list
+p2, m2, e2, l2, launched2 = run(True, steps=4, replay=True)
+p3, _, _, l3, _ = run(False, steps=4)
 out = dict(backend=dist.get_backend(), world=dist.get_world_size(), collectives=launched, params_equal=bool(torch.equal(p0, p1)),
-           moments_equal=bool(torch.equal(m0, m1)), ema_equal=bool(torch.equal(e0, e1)), losses_equal=l0 == l1, loss=l1[-1])
+           moments_equal=bool(torch.equal(m0, m1)), ema_equal=bool(torch.equal(e0, e1)), losses_equal=l0 == l1, loss=l1[-1],
+           replay_collectives=launched2, replay_params_equal=bool(torch.equal(p2, p3)), replay_losses_equal=l2 == l3)
 print("NCCL_SINGLE_RANK " + json.dumps(out), flush=True)
 dist.destroy_process_group()

@@ -210,6 +210,8 @@ def test_single_rank_nccl_gradsync_is_bit_identical():
     assert out["backend"] == "nccl" and out["world"] == 1
     assert out["collectives"] >= 3 * 3, out                      # >= 3 chunks per step really went through RCCL
     assert out["params_equal"] and out["moments_equal"] and out["ema_equal"] and out["losses_equal"], out
+    # ... and the recorded / replayed step (bench.py's default) issues its collectives live on every replay and stays bit-identical
+    assert out["replay_collectives"] >= 4 * 3 and out["replay_params_equal"] and out["replay_losses_equal"], out
 
 
 def test_reserved_token_compaction_matches_masked_blocks(monkeypatch):
