@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 4
+#define PPF_ABI_VERSION 5
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -148,6 +148,20 @@ int ppf_th_softmax_mix(float* sp, void* a16, float* hm, const float* ww, const f
                        ppf_stream_t stream);
 int ppf_th_softmax_bwd(const float* prob, float* da, void* ds16, const float* ww, const float* wl, float* dww, float* dbw, float* dbl,
                        int B, int H, int N, int NP, int NPK, ppf_stream_t stream);
+/* Fused talking-heads attention (cait:119-126; replaces th_scores + th_softmax_mix and, in backward, the dA product + th_softmax_bwd +
+ * th_dwl: no (B,H,N,N) fp32 tensor is materialised).  ppf_th_fused_supported: 1 when (heads, tokens, width) is covered (K and V images
+ * of all heads must fit the 160 KiB LDS: head_dim in {32,48,64}, heads in {2,4}, N <= 224), else 0 -- callers then use the kernels above.
+ * ppf_th_fwd: a16 = bf16 proj_w(softmax(proj_l(scale q k^T))) [B][H][N][NPK], hm = its head mean [B][N][NP], rowmax / zinv [B][H][N] =
+ * softmax statistics of the mixed logits (saved for backward).
+ * ppf_th_bwd: ds16 = bf16 dS [B][H][N][NPK] from dout = dO [B*N][D]; partial (>= ppf_th_bwd_partial_floats floats) receives one row of
+ * parameter-gradient sums per workgroup; ppf_th_param_reduce adds their fixed-order (bit-reproducible) totals to dww, dbw, dbl, dwl. */
+int ppf_th_fused_supported(int H, int N, int D);
+int ppf_th_fwd(const void* qkv, const float* wl, const float* bl, const float* ww, const float* bw, void* a16, float* hm, float* rowmax,
+               float* zinv, int B, int H, int N, int D, int NP, int NPK, ppf_stream_t stream);
+size_t ppf_th_bwd_partial_floats(int B, int H, int N);
+int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* bl, const float* ww, const float* rowmax, const float* zinv,
+               void* ds16, float* partial, int B, int H, int N, int D, int NPK, ppf_stream_t stream);
+int ppf_th_param_reduce(const float* partial, int B, int H, int N, float* dww, float* dbw, float* dbl, float* dwl, ppf_stream_t stream);
 /* class attention: q [B][D] (cls rows, unscaled), k/v [B*N1][D] bf16; policy softmax WITHOUT the identity term (cait:58-59) */
 int ppf_class_attn_fwd(const void* q, const void* k, const void* v, const float* policy, float* attn, float* zinv, float* rowmean,
                        void* out, int B, int H, int N1, int D, ppf_stream_t stream);

@@ -49,6 +49,9 @@ SIGS = {
     "ppf_th_dwl": "ppp" "iiiii" "s",
     "ppf_th_softmax_mix": "ppppp" "iiiii" "s",
     "ppf_th_softmax_bwd": "pppppppp" "iiiii" "s",
+    "ppf_th_fwd": "ppppppppp" "iiiiii" "s",
+    "ppf_th_bwd": "ppppppppp" "iiiii" "s",
+    "ppf_th_param_reduce": "p" "iii" "pppp" "s",
     "ppf_class_attn_fwd": "pppppppp" "iiii" "s",
     "ppf_class_attn_bwd": "ppppppppp" "iiii" "s",
     "ppf_merge3_cast": "pppp" "iii" "s",
@@ -74,7 +77,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 4               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 5               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
@@ -110,6 +113,10 @@ def lib():
         _lib.ppf_clip_grad_blocks.argtypes = []
         _lib.ppf_rowgemm_supported.restype = ctypes.c_int
         _lib.ppf_rowgemm_supported.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_th_fused_supported.restype = ctypes.c_int
+        _lib.ppf_th_fused_supported.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_th_bwd_partial_floats.restype = ctypes.c_size_t
+        _lib.ppf_th_bwd_partial_floats.argtypes = [ctypes.c_int] * 3
         _lib.ppf_stream_mark.restype = ctypes.c_int64
         _lib.ppf_stream_mark.argtypes = [ctypes.c_void_p]
         for name, spec in SIGS.items():

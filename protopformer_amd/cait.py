@@ -110,8 +110,13 @@ def cait_embed(feats, store, img, saved=None):
 def _th_attention_fwd(blk, qkv, B, H, N, D, hm_slot):
     """Talking-heads attention (cait:115-130) from packed qkv; returns (out bf16 [B*N,D], P fp32, A bf16)."""
     hd = D // H
-    sp = ops.th_scores(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, B, H, N, D)
-    a16 = ops.th_softmax_mix(sp, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot)      # sp now holds P
+    if ops.th_fused_ok(H, N, D):
+        # one launch, nothing of size N x N in fp32: only the softmax statistics are kept for backward
+        a16, rowmax, zinv = ops.th_fwd(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot, B, H, N, D)
+        sp = (rowmax, zinv)
+    else:
+        sp = ops.th_scores(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, B, H, N, D)
+        a16 = ops.th_softmax_mix(sp, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot)      # sp now holds P
     NPK = a16.shape[-1]
     ao = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
     # O_h[q][d] = sum_key A_h[q][key] V_h[key][d]
@@ -208,20 +213,29 @@ def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
     """Backward of the talking-heads attention: returns dqkv bf16 [B*N, 3D]; accumulates proj_l / proj_w grads."""
     hd = D // H
     qkv, prob, a16 = L["qkv"], L["prob"], L["a16"]
-    NP, NPK = prob.shape[-1], a16.shape[-1]
+    NPK = a16.shape[-1]
     dev = qkv.device
     scale = hd ** -0.5
     dqkv = torch.empty_like(qkv)
-    # dA_h[q][key] = sum_d dO_h[q][d] V_h[key][d]
-    da = torch.empty((B, H, N, NP), dtype=torch.float32, device=dev)
-    ops.gemm_batched(dao, ops._Off(qkv, 2 * D), da, N, N, hd, D, 3 * D, NP, False, False, True, 1.0, B, H,
-                     (N * D, hd), (N * 3 * D, hd), (H * N * NP, N * NP))
     # dV_h[key][d] = sum_q A_h[q][key] dO_h[q][d]
     ops.gemm_batched(a16, dao, ops._Off(dqkv, 2 * D), N, hd, N, NPK, D, 3 * D, True, True, False, 1.0, B, H,
                      (H * N * NPK, N * NPK), (N * D, hd), (N * 3 * D, hd), kpad=1)
-    ds16 = ops.th_softmax_bwd(prob, da, blk.attn.proj_w.weight, blk.attn.proj_l.weight, store.grad_view(blk.attn.proj_w.weight),
-                              store.grad_view(blk.attn.proj_w.bias), store.grad_view(blk.attn.proj_l.bias))
-    ops.th_dwl(qkv, da, store.grad_view(blk.attn.proj_l.weight), B, H, N, D)                # da now holds dS'
+    gv = store.grad_view
+    if isinstance(prob, tuple):
+        # fused: dA, the two head mixes and the softmax backward in registers; the parameter-gradient sums leave the main stream
+        rowmax, zinv = prob
+        ds16, partial = ops.th_bwd(qkv, dao, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, rowmax, zinv, B, H, N, D)
+        wgrad_lane(store).submit(lambda: ops.th_param_reduce(partial, B, H, N, gv(blk.attn.proj_w.weight), gv(blk.attn.proj_w.bias), gv(blk.attn.proj_l.bias),
+                                                             gv(blk.attn.proj_l.weight)), (partial,))
+    else:
+        NP = prob.shape[-1]
+        # dA_h[q][key] = sum_d dO_h[q][d] V_h[key][d]
+        da = torch.empty((B, H, N, NP), dtype=torch.float32, device=dev)
+        ops.gemm_batched(dao, ops._Off(qkv, 2 * D), da, N, N, hd, D, 3 * D, NP, False, False, True, 1.0, B, H,
+                         (N * D, hd), (N * 3 * D, hd), (H * N * NP, N * NP))
+        ds16 = ops.th_softmax_bwd(prob, da, blk.attn.proj_w.weight, blk.attn.proj_l.weight, gv(blk.attn.proj_w.weight), gv(blk.attn.proj_w.bias),
+                                  gv(blk.attn.proj_l.bias))
+        ops.th_dwl(qkv, da, gv(blk.attn.proj_l.weight), B, H, N, D)                # da now holds dS'
     # dQ_h = scale * dS_h K_h ;  dK_h = scale * dS_h^T Q_h
     ops.gemm_batched(ds16, ops._Off(qkv, D), dqkv, N, hd, N, NPK, 3 * D, 3 * D, False, True, False, scale, B, H,
                      (H * N * NPK, N * NPK), (N * 3 * D, hd), (N * 3 * D, hd), kpad=1)

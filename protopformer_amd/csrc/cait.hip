@@ -425,6 +425,391 @@ __global__ __launch_bounds__(256) void merge3_cast_kernel(const float* a, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused talking heads
+// One launch per direction instead of the materialised (B,H,N,N) fp32 logits / probabilities / gradients of the kernels above
+// (th_scores -> th_softmax_mix, and dA GEMM -> th_softmax_bwd -> th_dwl).  A wave owns 16 queries; K (and V in backward) of ALL heads of
+// the sample sit in LDS, and the score tiles of the H heads are recomputed on the MFMA pipe in every pass -- the pipe is idle otherwise.
+// v_mfma_f32_16x16x32_bf16 with "swapped" operands (first = 16 keys, second = 16 queries): a lane owns ONE query (lane & 15) and four
+// consecutive keys (4 * (lane >> 4) ..) of every 16-key tile, for all H heads at once -- 4 x H accumulator registers per tile -- which is what
+// the two head mixes need (they combine the H heads of one (query, key) position), and the softmax reductions are in-lane plus two
+// cross-group shuffles.  (The forward kernel processes two key tiles per loop trip, the backward kernel one: registers.)  head_dim = 48 runs as one full 32-wide contraction step and one half
+// step (the lanes that would hold d >= 48 pass zeros; the LDS rows stay 96 bytes).
+// A first version with 32x32x16 tiles (32 queries per wave, 16 registers per head and tile) needed > 256 VGPRs in backward (both the
+// score and the dA tiles of all heads are live in the elementwise stage), spilled, and ran one wave per SIMD: 184 us; see
+// profiles/r3_cait.txt.
+// Saved for backward: row maximum and 1 / sum of the mixed logits per (b, g, q) and the bf16 mixed probabilities A (operand of the
+// dV product); nothing else of size N x N.
+struct ThFusedParams {
+    const bf16_t* qkv;      // [B*N][3D]
+    const bf16_t* dout;     // [B*N][D]            backward
+    const float* wl; const float* bl; const float* ww; const float* bw;
+    bf16_t* a16;            // fwd out [B][H][N][NPK]   A_g = sum_h Ww[g,h] P_h + bw[g]
+    float* hm;              // fwd out [B][N][NP]       mean over heads of A
+    float* rowmax;          // [B][H][N]  fwd out / bwd in
+    float* zinv;            // [B][H][N]
+    bf16_t* ds16;           // bwd out [B][H][N][NPK]   dS_h = sum_g Wl[g,h] dS'_g
+    float* partial;         // bwd out [workgroups][2*H*H + 2*H]: dWw | dbw | dbl | dWl
+    int B, N, D, NP, NPK;
+    float scale;
+};
+constexpr float TH_LOG2E = 1.44269504088896340736f;
+constexpr int TH_WAVES = 7, TH_NTHR = TH_WAVES * 64;      // 7 x 16 = 112 queries per workgroup: N = 196 -> 2 workgroups per sample
+
+// [H][N][HD] bf16 image of one third (K or V) of the sample's packed qkv rows; global reads are row-contiguous
+template <int HD, int H>
+__device__ __forceinline__ void th_stage(unsigned char* img, const bf16_t* src, int N, int ld, int tid) {
+    constexpr int CH = HD / 8, RC = H * CH;
+    for (int i = tid; i < N * RC; i += TH_NTHR) {
+        const int row = i / RC, c24 = i - row * RC, h = c24 / CH, c = c24 - h * CH;
+        *reinterpret_cast<uint4*>(img + ((size_t)(h * N + row) * HD + c * 8) * 2) = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c24 * 8);
+    }
+}
+// first MFMA operand from an LDS image: row key_base + (lane & 15) (clamped to the last valid row: finite values, masked by the caller),
+// contraction slots 32 ks + 8 (lane >> 4) .. + 7 (zeros beyond the head dimension)
+template <int HD>
+__device__ __forceinline__ bf16x8 th_frag(const unsigned char* img, int N, int h, int key_base, int ks, int lane) {
+    const int row = min(key_base + (lane & 15), N - 1), k0 = 32 * ks + 8 * (lane >> 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (HD % 32 == 0 || k0 < HD) v = *reinterpret_cast<const uint4*>(img + ((size_t)(h * N + row) * HD + k0) * 2);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// second MFMA operand straight from global memory: row `row` of a [rows][ld] bf16 matrix, columns col0 + (same slots)
+template <int HD>
+__device__ __forceinline__ bf16x8 th_frag_global(const bf16_t* src, size_t row, int ld, int col0, int ks, int lane, bool live) {
+    const int k0 = 32 * ks + 8 * (lane >> 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (live && (HD % 32 == 0 || k0 < HD)) v = *reinterpret_cast<const uint4*>(src + row * ld + col0 + k0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// grid (ceil(ceil(N / 16) / 7), B), 7 waves; LDS: K image of all heads
+template <int HD, int H>
+__global__ __launch_bounds__(TH_NTHR, 1) void th_fwd_kernel(const ThFusedParams p) {
+    constexpr int KS = (HD + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_lds[];
+    unsigned char* tK = th_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
+    const int b = blockIdx.y, N = p.N, NT2 = (N + 31) / 32;
+    const bf16_t* base = p.qkv + (size_t)b * N * 3 * p.D;
+    const int q0 = (blockIdx.x * TH_WAVES + wave) * 16, q = q0 + (lane & 15), qc = min(q, N - 1);
+    bf16x8 qf[H][KS];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[h][ks] = th_frag_global<HD>(base, (size_t)qc, 3 * p.D, h * HD, ks, lane, true);
+    th_stage<HD, H>(tK, base + p.D, N, 3 * p.D, tid);
+    float wl[H][H], ww[H][H], blv[H], bwv[H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+        blv[g] = p.bl[g]; bwv[g] = p.bw[g];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { wl[g][h] = p.wl[g * H + h] * p.scale; ww[g][h] = p.ww[g * H + h]; }
+    }
+    __syncthreads();
+    if (q0 >= N) return;
+    // pass 1: running maximum and sum of exp of the mixed logits, per head, over this lane's keys
+    float m[H], l[H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) { m[g] = -1e30f; l[g] = 0.f; }
+#pragma unroll 1
+    for (int t2 = 0; t2 < NT2; ++t2) {
+        f32x4 s[2][H];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                s[u][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    s[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tK, N, h, t2 * 32 + u * 16, ks, lane), qf[h][ks], s[u][h], 0, 0, 0);
+            }
+        float o[H][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool valid = t2 * 32 + u * 16 + 4 * grp + i < N;
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    float a = blv[g];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) a += wl[g][h] * s[u][h][i];
+                    o[g][u * 4 + i] = valid ? a : -INFINITY;
+                }
+            }
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            float mt = m[g];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) mt = fmaxf(mt, o[g][r]);
+            float acc = l[g] * __builtin_amdgcn_exp2f((m[g] - mt) * TH_LOG2E);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc += __builtin_amdgcn_exp2f((o[g][r] - mt) * TH_LOG2E);
+            l[g] = acc; m[g] = mt;
+        }
+    }
+    float m2[H], zi[H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+        float mm = m[g], sum = l[g];
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float mo = __shfl_xor(mm, sh, 64), lo = __shfl_xor(sum, sh, 64);
+            const float mn = fmaxf(mm, mo);
+            sum = sum * __builtin_amdgcn_exp2f((mm - mn) * TH_LOG2E) + lo * __builtin_amdgcn_exp2f((mo - mn) * TH_LOG2E);
+            mm = mn;
+        }
+        m2[g] = mm * TH_LOG2E; zi[g] = 1.0f / sum;
+        if (grp == 0 && q < N) {
+            const size_t si = ((size_t)b * H + g) * N + q;
+            p.rowmax[si] = mm; p.zinv[si] = zi[g];
+        }
+    }
+    // pass 2: P_g = softmax(S'_g), A_g = sum_h Ww[g,h] P_h + bw[g]  ->  bf16 operand of A.V and the head mean (rollout input)
+    const float ih = 1.0f / (float)H;
+#pragma unroll 1
+    for (int t2 = 0; t2 < NT2; ++t2) {
+        f32x4 s[2][H];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                s[u][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    s[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tK, N, h, t2 * 32 + u * 16, ks, lane), qf[h][ks], s[u][h], 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int key0 = t2 * 32 + u * 16 + 4 * grp;
+            float av[H][4], mean[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool valid = key0 + i < N;
+                float pr[H];
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    float a = blv[g];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) a += wl[g][h] * s[u][h][i];
+                    pr[g] = valid ? __builtin_amdgcn_exp2f(a * TH_LOG2E - m2[g]) * zi[g] : 0.f;
+                }
+                float mu = 0.f;
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    float a = bwv[g];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) a += ww[g][h] * pr[h];
+                    a = valid ? a : 0.f;
+                    av[g][i] = a; mu += a;
+                }
+                mean[i] = mu * ih;
+            }
+            if (q < N) {
+                if (key0 < p.NPK) {
+#pragma unroll
+                    for (int g = 0; g < H; ++g)
+                        *reinterpret_cast<uint2*>(p.a16 + (((size_t)b * H + g) * N + q) * p.NPK + key0) =
+                            make_uint2(pack_bf16x2(av[g][0], av[g][1]), pack_bf16x2(av[g][2], av[g][3]));
+                }
+                if (key0 < p.NP) *reinterpret_cast<float4*>(p.hm + ((size_t)b * N + q) * p.NP + key0) = make_float4(mean[0], mean[1], mean[2], mean[3]);
+            }
+        }
+    }
+}
+
+// Backward of  A = proj_w(softmax(proj_l(scale q k^T)))  given dO: everything between the dA = dO V^T product and dS, in registers.
+//   dA_g = dO_g V_g^T;  dP_h = sum_g Ww[g,h] dA_g;  dS'_h = P_h (dP_h - sum_key dP_h P_h);  dS_h = sum_g Wl[g,h] dS'_g   (written, bf16)
+//   dWw[g,h] = sum dA_g P_h;  dbw[g] = sum dA_g;  dbl[h] = sum dS'_h;  dWl[g,h] = sum dS'_g (scale q_h k_h)           (per-workgroup partials)
+// Pass 1 accumulates the softmax-backward row term, pass 2 recomputes the tiles and emits.  Same grid as the forward kernel; LDS: the K and
+// V images of all heads (2 * H * N * HD * 2 bytes: 150.5 KB for CaiT-XXS) -> one workgroup of 7 waves per CU.
+template <int HD, int H>
+__global__ __launch_bounds__(TH_NTHR, 1) void th_bwd_kernel(const ThFusedParams p) {
+    constexpr int KS = (HD + 31) / 32, PW = 2 * H * H + 2 * H;
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4;
+    const int b = blockIdx.y, N = p.N, NT = (N + 15) / 16;
+    unsigned char* tK = th_lds;
+    unsigned char* tV = th_lds + (size_t)H * N * HD * 2;
+    float* red = reinterpret_cast<float*>(th_lds + (size_t)2 * H * N * HD * 2);       // [TH_WAVES][PW]
+    const bf16_t* base = p.qkv + (size_t)b * N * 3 * p.D;
+    const int q0 = (blockIdx.x * TH_WAVES + wave) * 16, q = q0 + (lane & 15), qc = min(q, N - 1);
+    const bool qvalid = q < N;
+    bf16x8 qf[H][KS], dof[H][KS];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[h][ks] = th_frag_global<HD>(base, (size_t)qc, 3 * p.D, h * HD, ks, lane, true);
+            dof[h][ks] = th_frag_global<HD>(p.dout, (size_t)b * N + qc, p.D, h * HD, ks, lane, qvalid);      // padded queries: dA = 0
+        }
+    th_stage<HD, H>(tK, base + p.D, N, 3 * p.D, tid);
+    th_stage<HD, H>(tV, base + 2 * p.D, N, 3 * p.D, tid);
+    float wl[H][H], ww[H][H], blv[H], m2[H], zi[H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+        blv[g] = p.bl[g];
+        const size_t si = ((size_t)b * H + g) * N + qc;
+        m2[g] = p.rowmax[si] * TH_LOG2E;
+        zi[g] = qvalid ? p.zinv[si] : 0.f;                                    // padded queries: P = 0
+#pragma unroll
+        for (int h = 0; h < H; ++h) { wl[g][h] = p.wl[g * H + h]; ww[g][h] = p.ww[g * H + h]; }
+    }
+    __syncthreads();
+    float acc[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) acc[i] = 0.f;
+    if (q0 < N) {
+        float dot[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) dot[h] = 0.f;
+        // pass 1: dot_h = sum_key dP_h P_h
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f32x4 s[1][H], da[1][H];
+#pragma unroll
+            for (int u = 0; u < 1; ++u)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    s[u][h] = f32x4{0.f, 0.f, 0.f, 0.f}; da[u][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tK, N, h, t * 16, ks, lane), qf[h][ks], s[u][h], 0, 0, 0);
+                        da[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tV, N, h, t * 16, ks, lane), dof[h][ks], da[u][h], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 1; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool valid = t * 16 + 4 * grp + i < N;
+                    float pr[H];
+#pragma unroll
+                    for (int g = 0; g < H; ++g) {
+                        float a = blv[g];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) a += wl[g][h] * (s[u][h][i] * p.scale);
+                        pr[g] = valid ? __builtin_amdgcn_exp2f(a * TH_LOG2E - m2[g]) * zi[g] : 0.f;
+                    }
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        float dp = 0.f;
+#pragma unroll
+                        for (int g = 0; g < H; ++g) dp += ww[g][h] * da[u][g][i];
+                        dot[h] += dp * pr[h];
+                    }
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            dot[h] += __shfl_xor(dot[h], 16, 64);
+            dot[h] += __shfl_xor(dot[h], 32, 64);
+        }
+        // pass 2: recompute the tiles, emit dS and the parameter-gradient sums
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f32x4 s[1][H], da[1][H];
+#pragma unroll
+            for (int u = 0; u < 1; ++u)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    s[u][h] = f32x4{0.f, 0.f, 0.f, 0.f}; da[u][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tK, N, h, t * 16, ks, lane), qf[h][ks], s[u][h], 0, 0, 0);
+                        da[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tV, N, h, t * 16, ks, lane), dof[h][ks], da[u][h], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 1; ++u) {
+                const int key0 = t * 16 + 4 * grp;
+                float dsv[H][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool valid = key0 + i < N;
+                    float sr[H], pr[H], dav[H], dsp[H];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) sr[h] = s[u][h][i] * p.scale;
+#pragma unroll
+                    for (int g = 0; g < H; ++g) {
+                        float a = blv[g];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) a += wl[g][h] * sr[h];
+                        pr[g] = valid ? __builtin_amdgcn_exp2f(a * TH_LOG2E - m2[g]) * zi[g] : 0.f;
+                        dav[g] = valid ? da[u][g][i] : 0.f;
+                    }
+#pragma unroll
+                    for (int g = 0; g < H; ++g) {
+                        acc[H * H + g] += dav[g];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) acc[g * H + h] += dav[g] * pr[h];
+                    }
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        float dp = 0.f;
+#pragma unroll
+                        for (int g = 0; g < H; ++g) dp += ww[g][h] * dav[g];
+                        dsp[h] = pr[h] * (dp - dot[h]);
+                        acc[H * H + H + h] += dsp[h];
+                    }
+#pragma unroll
+                    for (int g = 0; g < H; ++g)
+#pragma unroll
+                        for (int h = 0; h < H; ++h) acc[H * H + 2 * H + g * H + h] += dsp[g] * sr[h];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int g = 0; g < H; ++g) a += wl[g][h] * dsp[g];
+                        dsv[h][i] = a;
+                    }
+                }
+                if (qvalid && key0 < p.NPK) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+                        *reinterpret_cast<uint2*>(p.ds16 + (((size_t)b * H + h) * N + q) * p.NPK + key0) =
+                            make_uint2(pack_bf16x2(dsv[h][0], dsv[h][1]), pack_bf16x2(dsv[h][2], dsv[h][3]));
+                }
+            }
+        }
+    }
+    // parameter-gradient partials: wave -> workgroup, one slot row per workgroup (summed in a fixed order by th_param_reduce_kernel)
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave * PW + i] = v;
+    }
+    __syncthreads();
+    if (tid < PW) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < TH_WAVES; ++w) v += red[w * PW + tid];
+        p.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PW + tid] = v;
+    }
+}
+
+// out_j += sum over the workgroups' partial rows, fixed order (bit-reproducible): one workgroup per parameter-gradient element
+__global__ __launch_bounds__(256) void th_param_reduce_kernel(const float* __restrict__ partial, int nparts, int PW, int H, float* dww, float* dbw,
+                                                              float* dbl, float* dwl) {
+    __shared__ float red[256];
+    const int j = blockIdx.x, t = threadIdx.x;
+    float a = 0.f;
+    for (int i = t; i < nparts; i += 256) a += partial[(size_t)i * PW + j];
+    red[t] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) {
+        float* dst = j < H * H ? dww + j : j < H * H + H ? dbw + (j - H * H) : j < H * H + 2 * H ? dbl + (j - H * H - H) : dwl + (j - H * H - 2 * H);
+        *dst += red[0];
+    }
+}
+
+// workgroups per sample of the fused kernels: 16 queries per wave, TH_WAVES waves
+inline int th_groups(int N) { return ((N + 15) / 16 + TH_WAVES - 1) / TH_WAVES; }
+
 template <typename F>
 int dispatch_th(int hd, int H, const char* who, F&& f) {
 #define PPF_TH_CASE(HDV, HV) if (hd == HDV && H == HV) return f(std::integral_constant<int, HDV>(), std::integral_constant<int, HV>());
@@ -486,6 +871,64 @@ int ppf_th_softmax_bwd(const float* prob, float* da, void* ds16, const float* ww
     if (H == 4) hipLaunchKernelGGL(th_softmax_bwd_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
     else if (H == 2) hipLaunchKernelGGL(th_softmax_bwd_kernel<2>, dim3(grid), dim3(256), 0, stream, p);
     else { ppf_set_error("ppf_th_softmax_bwd: heads must be 2 or 4"); return PPF_ERR_SHAPE; }
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Fused talking-heads attention, forward part up to the mixed probabilities (cait:119-126): from packed qkv [B*N][3D] computes
+// A = proj_w(softmax(proj_l(scale q k^T))) as bf16 a16 [B][H][N][NPK] (zero padded; the operand of the A.V product), its head mean
+// hm [B][N][NP] (rollout input, cait:228) and the softmax statistics rowmax / zinv [B][H][N] the backward kernel recomputes P from.
+// Returns PPF_ERR_SHAPE for (head_dim, heads, N) combinations it does not cover (see ppf_th_fused_supported).
+int ppf_th_fused_supported(int H, int N, int D) {
+    if (H <= 0 || D % H != 0) return 0;
+    const int hd = D / H;
+    if (!((hd == 32 || hd == 48 || hd == 64) && (H == 2 || H == 4))) return 0;
+    if (N <= 0 || N > 224) return 0;
+    return (size_t)2 * H * N * hd * 2 + TH_WAVES * (2 * H * H + 2 * H) * sizeof(float) <= 160 * 1024 ? 1 : 0;
+}
+int ppf_th_fwd(const void* qkv, const float* wl, const float* bl, const float* ww, const float* bw, void* a16, float* hm, float* rowmax, float* zinv,
+               int B, int H, int N, int D, int NP, int NPK, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && ppf_th_fused_supported(H, N, D), PPF_ERR_SHAPE, "ppf_th_fwd: unsupported shape (B=%d H=%d N=%d D=%d)", B, H, N, D);
+    PPF_CHECK_ARG(NP % 4 == 0 && NPK % 8 == 0 && NPK >= NP && NP >= N && NPK <= 256, PPF_ERR_SHAPE, "ppf_th_fwd: bad padding");
+    ThFusedParams p = ThFusedParams(); p.qkv = (const bf16_t*)qkv; p.wl = wl; p.bl = bl; p.ww = ww; p.bw = bw; p.a16 = (bf16_t*)a16; p.hm = hm;
+    p.rowmax = rowmax; p.zinv = zinv; p.B = B; p.N = N; p.D = D; p.NP = NP; p.NPK = NPK; p.scale = 1.0f / sqrtf((float)(D / H));
+    return dispatch_th(D / H, H, "ppf_th_fwd", [&](auto hd, auto hv) {
+        constexpr int HD = decltype(hd)::value, HV = decltype(hv)::value;
+        const size_t lds = (size_t)HV * N * HD * 2;
+        auto k = th_fwd_kernel<HD, HV>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(k, dim3(th_groups(N), B), dim3(TH_NTHR), lds, stream, p);
+        PPF_LAUNCH_CHECK();
+        return 0;
+    });
+}
+// Backward of the same: dout = dO bf16 [B*N][D]; writes ds16 = bf16 dS [B][H][N][NPK] (operand of the dQ / dK products) and one row of
+// parameter-gradient partials per workgroup into `partial` (>= ppf_th_bwd_partial_floats floats), then adds their fixed-order sums to
+// dww [H][H], dbw [H], dbl [H], dwl [H][H] (reduce_stream: the stream of that small reduction; it is ordered behind `stream` by the
+// caller when they differ -- pass the same stream for plain in-order use).
+size_t ppf_th_bwd_partial_floats(int B, int H, int N) { return (size_t)B * th_groups(N) * (2 * H * H + 2 * H); }
+int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* bl, const float* ww, const float* rowmax, const float* zinv, void* ds16,
+               float* partial, int B, int H, int N, int D, int NPK, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && ppf_th_fused_supported(H, N, D), PPF_ERR_SHAPE, "ppf_th_bwd: unsupported shape (B=%d H=%d N=%d D=%d)", B, H, N, D);
+    PPF_CHECK_ARG(NPK % 8 == 0 && NPK >= N && NPK <= 256, PPF_ERR_SHAPE, "ppf_th_bwd: bad padding");
+    ThFusedParams p = ThFusedParams(); p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.wl = wl; p.bl = bl; p.ww = ww; p.rowmax = (float*)rowmax;
+    p.zinv = (float*)zinv; p.ds16 = (bf16_t*)ds16; p.partial = partial; p.B = B; p.N = N; p.D = D; p.NPK = NPK; p.scale = 1.0f / sqrtf((float)(D / H));
+    return dispatch_th(D / H, H, "ppf_th_bwd", [&](auto hd, auto hv) {
+        constexpr int HD = decltype(hd)::value, HV = decltype(hv)::value;
+        const size_t lds = (size_t)2 * HV * N * HD * 2 + TH_WAVES * (2 * HV * HV + 2 * HV) * sizeof(float);
+        auto k = th_bwd_kernel<HD, HV>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(k, dim3(th_groups(N), B), dim3(TH_NTHR), lds, stream, p);
+        PPF_LAUNCH_CHECK();
+        return 0;
+    });
+}
+int ppf_th_param_reduce(const float* partial, int B, int H, int N, float* dww, float* dbw, float* dbl, float* dwl, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && (H == 2 || H == 4) && N > 0, PPF_ERR_SHAPE, "ppf_th_param_reduce: bad shape");
+    const int PW = 2 * H * H + 2 * H;
+    hipLaunchKernelGGL(th_param_reduce_kernel, dim3(PW), dim3(256), 0, stream, partial, B * th_groups(N), PW, H, dww, dbw, dbl, dwl);
     PPF_LAUNCH_CHECK();
     return 0;
 }

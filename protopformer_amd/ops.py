@@ -487,6 +487,36 @@ def th_dwl(qkv, ds_prime, dwl, B, H, N, D):
     _lib.call("ppf_th_dwl", qkv, ds_prime, dwl, B, H, N, D, ds_prime.shape[-1])
 
 
+def th_fused_ok(H, N, D):
+    """The fused talking-heads kernels (csrc/cait.hip th_fwd / th_bwd) cover this (heads, tokens, width)."""
+    return os.environ.get("PPF_TH_FUSED", "1") != "0" and bool(_lib.lib().ppf_th_fused_supported(H, N, D))
+
+
+def th_fwd(qkv, wl, bl, ww, bw, hm_out, B, H, N, D):
+    """cait:119-126 in one launch: returns (a16 bf16 [B,H,N,NPK] = proj_w(softmax(proj_l(scale q k^T))), rowmax, zinv [B,H,N]);
+    hm_out [B,N,NP] receives the head mean of the mixed probabilities (rollout input)."""
+    NP, NPK = (N + 3) // 4 * 4, (N + 7) // 8 * 8
+    a16 = torch.empty((B, H, N, NPK), dtype=torch.bfloat16, device=qkv.device)
+    rowmax = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    zinv = torch.empty_like(rowmax)
+    _lib.call("ppf_th_fwd", qkv, wl, bl, ww, bw, a16, hm_out, rowmax, zinv, B, H, N, D, NP, NPK)
+    return a16, rowmax, zinv
+
+
+def th_bwd(qkv, dout, wl, bl, ww, rowmax, zinv, B, H, N, D):
+    """Backward of th_fwd up to dS: returns (ds16 bf16 [B,H,N,NPK], partial) -- partial holds the per-workgroup parameter-gradient
+    sums for th_param_reduce."""
+    NPK = (N + 7) // 8 * 8
+    ds16 = torch.empty((B, H, N, NPK), dtype=torch.bfloat16, device=qkv.device)
+    partial = torch.empty((int(_lib.lib().ppf_th_bwd_partial_floats(B, H, N)),), dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_th_bwd", qkv, dout, wl, bl, ww, rowmax, zinv, ds16, partial, B, H, N, D, NPK)
+    return ds16, partial
+
+
+def th_param_reduce(partial, B, H, N, dww, dbw, dbl, dwl):
+    _lib.call("ppf_th_param_reduce", partial, B, H, N, dww, dbw, dbl, dwl)
+
+
 def class_attn_fwd(q, k, v, policy, B, H, N1, D, rowmean=None):
     dev = q.device
     attn = torch.empty((B, H, N1), dtype=torch.float32, device=dev)

@@ -10,22 +10,35 @@ from oracle import ppf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+class _P:
+    pass
+
+
+def _th_block(wl, bl, ww, bw):
+    """Minimal stand-in for a TalkingHeadAttn block: the two head-mixing layers."""
+    blk = _P(); blk.attn = _P(); blk.attn.proj_l = _P(); blk.attn.proj_w = _P()
+    blk.attn.proj_l.weight, blk.attn.proj_l.bias = wl.cuda().contiguous(), bl.cuda()
+    blk.attn.proj_w.weight, blk.attn.proj_w.bias = ww.cuda().contiguous(), bw.cuda()
+    return blk
+
+
 def _th_forward(qkv16, wl, bl, ww, bw, B, H, N, D):
-    from protopformer_amd import ops
-    hd = D // H
-    sp = ops.th_scores(qkv16, wl, bl, B, H, N, D)
-    hm = torch.empty((B, N, sp.shape[-1]), dtype=torch.float32, device="cuda")
-    a16 = ops.th_softmax_mix(sp, ww, bw, hm)
-    NPK = a16.shape[-1]
-    ao = torch.empty((B * N, D), dtype=torch.bfloat16, device="cuda")
-    ops.gemm_batched(a16, ops._Off(qkv16, 2 * D), ao, N, hd, N, NPK, 3 * D, D, False, True, False, 1.0, B, H,
-                     (H * N * NPK, N * NPK), (N * 3 * D, hd), (N * D, hd), kpad=1)
-    return ao, sp, a16, hm
+    """The product's forward helper (fused kernel or the materialising kernels, PPF_TH_FUSED): (ao, saved statistics / P, a16, head mean)."""
+    from protopformer_amd.cait import _th_attention_fwd
+    hm = torch.empty((B, N, (N + 3) // 4 * 4), dtype=torch.float32, device="cuda")
+    ao, prob, a16 = _th_attention_fwd(_th_block(wl, bl, ww, bw), qkv16, B, H, N, D, hm)
+    return ao, prob, a16, hm
 
 
-def test_talking_heads_forward_golden():
+FUSED = pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "materialised"])
+
+
+@FUSED
+def test_talking_heads_forward_golden(fused, monkeypatch):
     """TalkingHeadAttn.forward on the reference's weights/inputs (ops_real.npz), qkv/proj through the GEMM kernel."""
     from protopformer_amd import ops
+    monkeypatch.setenv("PPF_TH_FUSED", fused)
+    assert ops.th_fused_ok(4, 196, 192) == (fused == "1")
     z = load_npz("ops_real.npz")
     c = gi.cait_inputs()
     B, H, N, D = c["B"], c["H"], c["N"], c["D"]
@@ -44,8 +57,10 @@ def test_talking_heads_forward_golden():
     assert rel_err(hm[..., :N], p_ref.mean(1)) < 2e-2, rel_err(hm[..., :N], p_ref.mean(1))
 
 
-def test_talking_heads_backward_vs_oracle():
+@FUSED
+def test_talking_heads_backward_vs_oracle(fused, monkeypatch):
     from protopformer_amd import ops
+    monkeypatch.setenv("PPF_TH_FUSED", fused)
     B, H, N, D = 2, 4, 196, 192
     hd = D // H
     g = torch.Generator().manual_seed(3)
@@ -67,19 +82,21 @@ def test_talking_heads_backward_vs_oracle():
     # HIP path
     from protopformer_amd.cait import _th_attention_bwd
 
-    class _S:                                   # minimal stand-ins for the store / block the helper expects
+    class _S:                                   # minimal stand-in for the flat store the helper expects
+        device = torch.device("cuda", 0)
         def __init__(self): self.g = {}
         def grad_view(self, p_): return self.g.setdefault(id(p_), torch.zeros_like(p_))
 
-    class _P:  pass
-    blk = _P(); blk.attn = _P(); blk.attn.proj_l = _P(); blk.attn.proj_w = _P()
-    blk.attn.proj_l.weight, blk.attn.proj_l.bias = wl.cuda().contiguous(), bl.cuda()
-    blk.attn.proj_w.weight, blk.attn.proj_w.bias = ww.cuda().contiguous(), bw.cuda()
+    blk = _th_block(wl, bl, ww, bw)
     qd = qkv.cuda()
     ao, prob, a16, hm = _th_forward(qd, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, blk.attn.proj_w.bias, B, H, N, D)
     assert rel_err(ao.float(), o.detach()) < 1.5e-2
     st = _S()
-    dqkv = _th_attention_bwd(st, blk, dict(qkv=qd, prob=prob, a16=a16), dao.cuda(), B, H, N, D).float().cpu()
+    dqkv = _th_attention_bwd(st, blk, dict(qkv=qd, prob=prob, a16=a16), dao.cuda(), B, H, N, D)
+    from protopformer_amd.backbone import wgrad_lane
+    wgrad_lane(st).join()                       # the fused path sums the parameter-gradient partials on the side stream
+    torch.cuda.synchronize()
+    dqkv = dqkv.float().cpu()
     scale = float(t.grad.abs().max())
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert_close(dqkv[:, sl], t.grad[:, sl], rtol=3e-2, atol=2e-2 * scale, what=name)
