@@ -84,8 +84,10 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
  * 208 rows, the host passes the tokens of one sample), so what the reference does next to those rows runs in the epilogue and the
  * GEMM output / the separate LayerNorm pass never touch HBM.  Both operands contraction-contiguous, bf16; K % 32 == 0.
  *   ppf_rowgemm_bf16      out bf16 = acc + bias                                   input gradient of attn.proj (autograd of deit:58)
- *   ppf_rowgemm_resid_ln  xout = res + rowscale[m / rows_per_group] * (acc + bias) (fp32, may alias res): `x = x + drop_path(attn(...))`
- *                         / `x = x + drop_path(mlp(...))` (deit:79-80, timm DropPath); ln_out = bf16(LN(xout)), mean, rstd = the
+ *   ppf_rowgemm_resid_ln  xout = res + rowscale[m / rows_per_group] * colscale[n] * (acc + bias) (fp32, may alias res):
+ *                         `x = x + drop_path(attn(...))` / `x = x + drop_path(mlp(...))` (deit:79-80, timm DropPath); colscale = CaiT's
+ *                         LayerScale gamma_1 / gamma_2 (cait:153-155) or NULL, aux_out (optional) = bf16(acc + bias), the unscaled
+ *                         branch its gradient needs; ln_out = bf16(LN(xout)), mean, rstd = the
  *                         LayerNorm that follows (deit:79 norm2 / the next block's norm1, eps 1e-6); ln_out == NULL: residual only
  *   ppf_rowgemm_lnbwd     dn = acc: gradient w.r.t. a LayerNorm output (input of qkv / fc1, deit:47 / timm Mlp fc1);
  *                         dx_out = dres_in + LN'(dn; x, mean, rstd, w) (fp32, may alias dres_in; NULL = 0);
@@ -96,8 +98,8 @@ int ppf_rowgemm_supported(int D, int K, int rows_per_tile);
 int ppf_rowgemm_bf16(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* bias, void* out,
                      ppf_stream_t stream);
 int ppf_rowgemm_resid_ln(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* bias,
-                         const float* res, float* xout, const float* rowscale, int rows_per_group, const float* ln_w, const float* ln_b,
-                         void* ln_out, float* ln_mean, float* ln_rstd, float eps, ppf_stream_t stream);
+                         const float* res, float* xout, const float* rowscale, int rows_per_group, const float* colscale, void* aux_out,
+                         const float* ln_w, const float* ln_b, void* ln_out, float* ln_mean, float* ln_rstd, float eps, ppf_stream_t stream);
 int ppf_rowgemm_lnbwd(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* x, const float* mean,
                       const float* rstd, const float* w, const float* dres_in, float* dx_out, void* cast_out, const float* rowscale,
                       int rows_per_group, float* partial, size_t partial_bytes, ppf_stream_t stream);

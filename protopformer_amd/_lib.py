@@ -14,7 +14,7 @@ SIGS = {
     "ppf_gemm_bf16": "pppiiiiiiiiippipipppipf" "pz" "s",
     "ppf_device_info": "pppi",
     "ppf_rowgemm_bf16": "pp" "iiiiii" "pp" "s",
-    "ppf_rowgemm_resid_ln": "pp" "iiiiii" "p" "pp" "pi" "pp" "ppp" "f" "s",
+    "ppf_rowgemm_resid_ln": "pp" "iiiiii" "p" "pp" "pi" "pp" "pp" "ppp" "f" "s",
     "ppf_rowgemm_lnbwd": "pp" "iiiiii" "pppp" "ppp" "pi" "pz" "s",
     "ppf_rowgemm_colsum": "p" "ii" "pp" "s",
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",

@@ -7,6 +7,7 @@ proj_l,proj_w},norm2,mlp.{fc1,fc2}}``, ``blocks_token_only.{i}.{gamma_1,gamma_2,
 ``(1,Np,D)``, ``cls_token``, ``norm``).  nn modules are parameter containers only; all arithmetic is in csrc/cait.hip + the GEMMs.
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -138,21 +139,37 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     lane = wgrad_lane(store)
     layers = []
     x = x.reshape(M, D)
+    # The projection / fc2 GEMM, the LayerScale residual and the LayerNorm that follows run as one full-row kernel (csrc/rowgemm.hip) where
+    # the shape is covered: `pre` carries the next block's norm1 output out of the previous block's fc2 launch.
+    rowk = (os.environ.get("PPF_CAIT_ROWGEMM", "1") != "0" and bool(feats.blocks) and ops.rowgemm_ok(D, D, N)
+            and ops.rowgemm_ok(D, feats.blocks[0].mlp.fc1.out_features, N))
+    pre = None
     for i, blk in enumerate(feats.blocks):
-        n1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, prob, a16 = _th_attention_fwd(blk, qkv, B, H, N, D, hm[i])
         lane.submit(lambda i=i: ops.rollout_threshold(hm[i], thr[i], N), (hm, thr))      # the rollout's order statistic, off the critical path
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
-        x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N,
-                      colscale=blk.gamma_1, aux_out=raw1)
-        n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        if rowk:
+            x1, n2, mean2, rstd2 = ops.rowgemm_resid_ln(ao, store.w16(blk.attn.proj.weight), x, N, bias=blk.attn.proj.bias, rowscale=s1, rows_per_group=N,
+                                                        ln_w=blk.norm2.weight, ln_b=blk.norm2.bias, eps=LN_EPS, colscale=blk.gamma_1, aux_out=raw1)
+        else:
+            x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N,
+                          colscale=blk.gamma_1, aux_out=raw1)
+            n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
         h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
         raw2 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
-        x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=N,
-                      colscale=blk.gamma_2, aux_out=raw2)
+        nxt = feats.blocks[i + 1] if i + 1 < depth else None
+        if rowk:
+            x2, nn1, nm1, nr1 = ops.rowgemm_resid_ln(g, store.w16(blk.mlp.fc2.weight), x1, N, bias=blk.mlp.fc2.bias, rowscale=s2, rows_per_group=N,
+                                                     ln_w=nxt.norm1.weight if nxt is not None else None, ln_b=nxt.norm1.bias if nxt is not None else None,
+                                                     eps=LN_EPS, colscale=blk.gamma_2, aux_out=raw2)
+            pre = (nn1, nm1, nr1) if nxt is not None else None
+        else:
+            x2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=x1, rowscale=s2, rows_per_group=N,
+                          colscale=blk.gamma_2, aux_out=raw2)
         if save:
             layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, prob=prob, a16=a16, ao=ao, x1=x1, n2=n2, mean2=mean2,
                                rstd2=rstd2, h=h, g=g, raw1=raw1, raw2=raw2, s1=s1, s2=s2))

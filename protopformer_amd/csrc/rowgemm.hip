@@ -53,8 +53,9 @@ struct RowGemmParams {
     const float* bias;             // [D] added to the accumulator, or null
     // RG_BF16: out16 = bf16(acc + bias)
     bf16_t* out16;
-    // RG_RESID_LN: xout = res + rowscale[m / rows_per_group] * (acc + bias);  ln_out = bf16(LN(xout) * ln_w + ln_b), mean / rstd per row
-    const float* res; float* xout; const float* rowscale; int rows_per_group;
+    // RG_RESID_LN: xout = res + rowscale[m / rows_per_group] * colscale[n] * (acc + bias);  ln_out = bf16(LN(xout) * ln_w + ln_b), mean / rstd
+    //              per row; aux_out = bf16(acc + bias) (the unscaled branch: LayerScale's gradient needs it), colscale / aux_out optional
+    const float* res; float* xout; const float* rowscale; int rows_per_group; const float* colscale; bf16_t* aux_out;
     const float* ln_w; const float* ln_b; bf16_t* ln_out; float* ln_mean; float* ln_rstd; float eps;
     // RG_LNBWD: dn = acc (+ bias); dx_out = dres_in + LN'(dn; x, mean, rstd, w);  cast_out = bf16(rowscale * dx_out);
     //           partial[tile][0][n] = sum_m dn * xhat (d ln weight), partial[tile][1][n] = sum_m dn (d ln bias)
@@ -287,6 +288,19 @@ __global__ __launch_bounds__(RG_NTHR, 2) void rowgemm_kernel(const RowGemmParams
                         for (int e = 0; e < VW; ++e) ra[i][e] = 0.f;
                     }
                 }
+                if (p.aux_out && ok) {                                     // p.aux_out: uniform
+#pragma unroll
+                    for (int i = 0; i < NSEG; ++i) rg_st16<VW>(p.aux_out + m * D + VW * jl + PIECE * i, v[i]);
+                }
+                if (p.colscale) {                                          // uniform
+#pragma unroll
+                    for (int i = 0; i < NSEG; ++i) {
+                        float cs[VW];
+                        rg_ld<VW>(cs, p.colscale + VW * jl + PIECE * i);
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) v[i][e] *= cs[e];
+                    }
+                }
                 float s = 0.f;
 #pragma unroll
                 for (int i = 0; i < NSEG; ++i)
@@ -479,16 +493,19 @@ int ppf_rowgemm_bf16(const void* A, const void* B, int M, int D, int K, int lda,
     return rg_run(p, D, RG_BF16, stream);
 }
 
-// Residual branch + the LayerNorm that follows it (deit:76-81): xout = res + rowscale[m / rows_per_group] * (A B^T + bias)  (fp32, may
-// alias res); ln_out = bf16(LN(xout) * ln_w + ln_b) with its row statistics (ln_out == NULL: no LayerNorm, the last block).
+// Residual branch + the LayerNorm that follows it (deit:76-81, cait:153-155): xout = res + rowscale[m / rows_per_group] * colscale[n] *
+// (A B^T + bias)  (fp32, may alias res; colscale = CaiT's LayerScale gamma or NULL); aux_out (optional) = bf16(A B^T + bias), the unscaled
+// branch the LayerScale gradient needs; ln_out = bf16(LN(xout) * ln_w + ln_b) with its row statistics (ln_out == NULL: no LayerNorm).
 int ppf_rowgemm_resid_ln(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* bias,
-                         const float* res, float* xout, const float* rowscale, int rows_per_group, const float* ln_w, const float* ln_b,
-                         void* ln_out, float* ln_mean, float* ln_rstd, float eps, hipStream_t stream) {
-    PPF_CHECK_ARG(A && B && res && xout && ((((uintptr_t)res) | ((uintptr_t)xout) | ((uintptr_t)ln_out)) & 15) == 0, PPF_ERR_ARG, "ppf_rowgemm_resid_ln: null / misaligned pointer");
+                         const float* res, float* xout, const float* rowscale, int rows_per_group, const float* colscale, void* aux_out,
+                         const float* ln_w, const float* ln_b, void* ln_out, float* ln_mean, float* ln_rstd, float eps, hipStream_t stream) {
+    PPF_CHECK_ARG(A && B && res && xout && ((((uintptr_t)res) | ((uintptr_t)xout) | ((uintptr_t)ln_out) | ((uintptr_t)aux_out) | ((uintptr_t)colscale)) & 15) == 0,
+                  PPF_ERR_ARG, "ppf_rowgemm_resid_ln: null / misaligned pointer");
     PPF_CHECK_ARG(ln_out == nullptr || (ln_w && ln_b && ln_mean && ln_rstd), PPF_ERR_ARG, "ppf_rowgemm_resid_ln: LayerNorm output needs weight, bias, mean and rstd");
     RowGemmParams p = {};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.K = K; p.lda = lda; p.ldb = ldb; p.rows_per_tile = rows_per_tile; p.bias = bias;
     p.res = res; p.xout = xout; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+    p.colscale = colscale; p.aux_out = (bf16_t*)aux_out;
     p.ln_w = ln_w; p.ln_b = ln_b; p.ln_out = (bf16_t*)ln_out; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd; p.eps = eps;
     return rg_run(p, D, RG_RESID_LN, stream);
 }

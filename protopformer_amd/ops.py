@@ -90,9 +90,10 @@ def rowgemm_bf16(a, b, rows_per_tile, bias=None):
     return out
 
 
-def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_per_group=1, ln_w=None, ln_b=None, eps=1e-6):
-    """x_out = res + rowscale * (a @ b^T + bias) (fp32) and, with ln_w / ln_b, n = bf16(LN(x_out)), mean, rstd of the LayerNorm that
-    follows.  Returns (x_out, n, mean, rstd) (the last three None without a LayerNorm)."""
+def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_per_group=1, ln_w=None, ln_b=None, eps=1e-6, colscale=None, aux_out=None):
+    """x_out = res + rowscale * colscale * (a @ b^T + bias) (fp32) and, with ln_w / ln_b, n = bf16(LN(x_out)), mean, rstd of the LayerNorm
+    that follows; aux_out (bf16 [M, D], optional) receives the unscaled branch a @ b^T + bias.
+    Returns (x_out, n, mean, rstd) (the last three None without a LayerNorm)."""
     _chk(a, torch.bfloat16), _chk(b, torch.bfloat16), _chk(res, torch.float32)
     M, K = a.shape
     D = b.shape[0]
@@ -102,8 +103,8 @@ def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_pe
         n = torch.empty((M, D), dtype=torch.bfloat16, device=a.device)
         mean = torch.empty(M, dtype=torch.float32, device=a.device)
         rstd = torch.empty(M, dtype=torch.float32, device=a.device)
-    _lib.call("ppf_rowgemm_resid_ln", a, b, M, D, K, K, b.shape[1], rows_per_tile, bias, res, xout, rowscale, rows_per_group, ln_w, ln_b, n, mean, rstd,
-              float(eps))
+    _lib.call("ppf_rowgemm_resid_ln", a, b, M, D, K, K, b.shape[1], rows_per_tile, bias, res, xout, rowscale, rows_per_group, colscale, aux_out,
+              ln_w, ln_b, n, mean, rstd, float(eps))
     return xout, n, mean, rstd
 
 

@@ -30,9 +30,12 @@ def test_rowgemm_bf16_and_transposed_shadow(M, D, K, rpt):
     assert rel_err(out.float().cpu(), ref) < 4e-3            # bf16 output rounding (2^-9) dominates; measured ~2e-3
 
 
-@pytest.mark.parametrize("M,D,K,rpt,with_ln", [(4 * 197, 384, 384, 197, True), (3 * 197, 384, 1536, 197, True), (5 * 82, 384, 1536, 82, False),
-                                               (2 * 196, 192, 768, 196, True), (3 * 197, 192, 192, 197, True)])
-def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln):
+@pytest.mark.parametrize("M,D,K,rpt,with_ln,layerscale", [(4 * 197, 384, 384, 197, True, False), (3 * 197, 384, 1536, 197, True, False),
+                                                          (5 * 82, 384, 1536, 82, False, False), (2 * 196, 192, 768, 196, True, False),
+                                                          (3 * 197, 192, 192, 197, True, False), (3 * 196, 192, 192, 196, True, True),
+                                                          (2 * 196, 192, 768, 196, False, True)])
+def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln, layerscale):
+    """layerscale: CaiT's per-channel gamma on the branch (cait:153-155) and the unscaled branch as a second (bf16) output."""
     from protopformer_amd import ops
     a, b, g = _mk(M, D, K, 2)
     bias = torch.randn(D, generator=g) * 0.1
@@ -40,12 +43,19 @@ def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln):
     B = M // rpt
     scale = torch.tensor([0.0, 1.0 / 0.9] * B)[:B].contiguous()                      # DropPath factors: dropped / kept
     lw, lb = 1.0 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
-    x_ref = res + scale.repeat_interleave(rpt)[:, None] * (a.float() @ b.float().t() + bias)
+    gamma = (0.5 + torch.rand(D, generator=g)) if layerscale else None
+    branch = a.float() @ b.float().t() + bias
+    x_ref = res + scale.repeat_interleave(rpt)[:, None] * (branch * gamma if layerscale else branch)
+    raw = torch.empty((M, D), dtype=torch.bfloat16, device="cuda") if layerscale else None
     xo, n, mean, rstd = ops.rowgemm_resid_ln(a.cuda(), b.cuda(), res.cuda(), rpt, bias=bias.cuda(), rowscale=scale.cuda(), rows_per_group=rpt,
-                                             ln_w=lw.cuda() if with_ln else None, ln_b=lb.cuda() if with_ln else None)
+                                             ln_w=lw.cuda() if with_ln else None, ln_b=lb.cuda() if with_ln else None,
+                                             colscale=gamma.cuda() if layerscale else None, aux_out=raw)
     torch.cuda.synchronize()
     e = dict(x=rel_err(xo.cpu(), x_ref))
     assert e["x"] < 1e-3
+    if layerscale:
+        e["raw"] = rel_err(raw.float().cpu(), branch)
+        assert e["raw"] < 4e-3                                                     # bf16 output
     if with_ln:
         n_ref = torch.nn.functional.layer_norm(x_ref, (D,), lw, lb, 1e-6)
         mu, var = x_ref.mean(-1), x_ref.var(-1, unbiased=False)
