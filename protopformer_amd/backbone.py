@@ -117,7 +117,8 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         M = B * Nc
         hid = blk.mlp.fc1.out_features
         # full-row GEMMs (csrc/rowgemm.hip): the residual products also emit the LayerNorm that follows them
-        fused = _ROW_FWD and ops.rowgemm_ok(D, D, Nc) and ops.rowgemm_ok(D, hid, Nc)
+        rpt = ops.rowgemm_tile_rows(B * Nc, Nc)
+        fused = _ROW_FWD and ops.rowgemm_ok(D, D, rpt) and ops.rowgemm_ok(D, hid, rpt)
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         pre = None
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
@@ -139,7 +140,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
                             (hm, thr) + rolled)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         if fused:
-            x1, n2, mean2, rstd2 = ops.rowgemm_resid_ln(ao, store.w16(blk.attn.proj.weight), x, Nc, bias=blk.attn.proj.bias, rowscale=s1, rows_per_group=Nc,
+            x1, n2, mean2, rstd2 = ops.rowgemm_resid_ln(ao, store.w16(blk.attn.proj.weight), x, rpt, bias=blk.attn.proj.bias, rowscale=s1, rows_per_group=Nc,
                                                         ln_w=blk.norm2.weight, ln_b=blk.norm2.bias, eps=LN_EPS)
         else:
             x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
@@ -149,7 +150,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         if fused:
             # the next block's norm1 rides on this block's fc2 product, unless the token gather of the reservation comes in between
             nxt = feats.blocks[i + 1] if (i + 1 < nblk and not (compact and i + 1 == reserve_layer)) else None
-            x2, nn1, nm1, nr1 = ops.rowgemm_resid_ln(g, store.w16(blk.mlp.fc2.weight), x1, Nc, bias=blk.mlp.fc2.bias, rowscale=s2, rows_per_group=Nc,
+            x2, nn1, nm1, nr1 = ops.rowgemm_resid_ln(g, store.w16(blk.mlp.fc2.weight), x1, rpt, bias=blk.mlp.fc2.bias, rowscale=s2, rows_per_group=Nc,
                                                      ln_w=nxt.norm1.weight if nxt is not None else None, ln_b=nxt.norm1.bias if nxt is not None else None,
                                                      eps=LN_EPS)
             pre = (nn1, nm1, nr1) if nxt is not None else None
@@ -339,8 +340,9 @@ def deit_backward(ppnet, store, saved, df):
         Nl = L["N"]                                       # tokens per sample in this block (1+k once compacted)
         hid = blk.mlp.fc1.out_features
         w1t, wqt, wpt = store.w16t(blk.mlp.fc1.weight), store.w16t(blk.attn.qkv.weight), store.w16t(blk.attn.proj.weight)
-        fused = (_row_bwd(B * Nl, D) and w1t is not None and wqt is not None and wpt is not None and ops.rowgemm_ok(D, hid, Nl) and ops.rowgemm_ok(D, 3 * D, Nl)
-                 and ops.rowgemm_ok(D, D, Nl))
+        rpt = ops.rowgemm_tile_rows(B * Nl, Nl, backward=True)
+        fused = (_row_bwd(B * Nl, D) and w1t is not None and wqt is not None and wpt is not None and ops.rowgemm_ok(D, hid, rpt) and ops.rowgemm_ok(D, 3 * D, rpt)
+                 and ops.rowgemm_ok(D, D, rpt))
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
         _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias)
         dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
@@ -348,7 +350,7 @@ def deit_backward(ppnet, store, saved, df):
         dyb, dyb_alt = next_dyb(dyb, dyb_alt)
         if fused:
             ops.rowgemm_lnbwd(dh, w1t, L["x1"], L["mean2"], L["rstd2"], blk.norm2.weight, store.grad_view(blk.norm2.weight), store.grad_view(blk.norm2.bias),
-                              Nl, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl, lane=lane, defer_reduce=True)
+                              rpt, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl, lane=lane, defer_reduce=True)
         else:
             dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
             lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
@@ -358,7 +360,7 @@ def deit_backward(ppnet, store, saved, df):
         # attention branch: x1 = x + s1 * (attn(n1) Wp^T + bp)
         _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, None if bias_done else blk.attn.proj.bias)
         if fused:
-            dao = ops.rowgemm_bf16(dyb, wpt, Nl)
+            dao = ops.rowgemm_bf16(dyb, wpt, rpt)
         else:
             dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
         dqkv = (torch.empty_like(L["qkv"]) if "attnbwd" in _KO else
@@ -370,7 +372,7 @@ def deit_backward(ppnet, store, saved, df):
             dyb, dyb_alt = next_dyb(dyb, dyb_alt)
             if fused:
                 ops.rowgemm_lnbwd(dqkv, wqt, L["x"], L["mean1"], L["rstd1"], blk.norm1.weight, store.grad_view(blk.norm1.weight), store.grad_view(blk.norm1.bias),
-                                  Nl, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"], rows_per_group=Nl, lane=lane, defer_reduce=True)
+                                  rpt, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"], rows_per_group=Nl, lane=lane, defer_reduce=True)
             else:
                 lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                                   store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=layers[i - 1]["s2"],
@@ -385,7 +387,7 @@ def deit_backward(ppnet, store, saved, df):
         else:
             if fused:
                 ops.rowgemm_lnbwd(dqkv, wqt, L["x"], L["mean1"], L["rstd1"], blk.norm1.weight, store.grad_view(blk.norm1.weight), store.grad_view(blk.norm1.bias),
-                                  Nl, dres_in=dx, dx_out=dx, lane=lane, defer_reduce=True)
+                                  rpt, dres_in=dx, dx_out=dx, lane=lane, defer_reduce=True)
             else:
                 lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], store.grad_view(blk.norm1.weight),
                                   store.grad_view(blk.norm1.bias), dres_in=dx, dx_out=dx)

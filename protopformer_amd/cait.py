@@ -141,8 +141,9 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     x = x.reshape(M, D)
     # The projection / fc2 GEMM, the LayerScale residual and the LayerNorm that follows run as one full-row kernel (csrc/rowgemm.hip) where
     # the shape is covered: `pre` carries the next block's norm1 output out of the previous block's fc2 launch.
-    rowk = (os.environ.get("PPF_CAIT_ROWGEMM", "1") != "0" and bool(feats.blocks) and ops.rowgemm_ok(D, D, N)
-            and ops.rowgemm_ok(D, feats.blocks[0].mlp.fc1.out_features, N))
+    rpt = ops.rowgemm_tile_rows(M, N)
+    rowk = (os.environ.get("PPF_CAIT_ROWGEMM", "1") != "0" and bool(feats.blocks) and ops.rowgemm_ok(D, D, rpt)
+            and ops.rowgemm_ok(D, feats.blocks[0].mlp.fc1.out_features, rpt))
     pre = None
     for i, blk in enumerate(feats.blocks):
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
@@ -152,7 +153,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         if rowk:
-            x1, n2, mean2, rstd2 = ops.rowgemm_resid_ln(ao, store.w16(blk.attn.proj.weight), x, N, bias=blk.attn.proj.bias, rowscale=s1, rows_per_group=N,
+            x1, n2, mean2, rstd2 = ops.rowgemm_resid_ln(ao, store.w16(blk.attn.proj.weight), x, rpt, bias=blk.attn.proj.bias, rowscale=s1, rows_per_group=N,
                                                         ln_w=blk.norm2.weight, ln_b=blk.norm2.bias, eps=LN_EPS, colscale=blk.gamma_1, aux_out=raw1)
         else:
             x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N,
@@ -163,7 +164,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         raw2 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         nxt = feats.blocks[i + 1] if i + 1 < depth else None
         if rowk:
-            x2, nn1, nm1, nr1 = ops.rowgemm_resid_ln(g, store.w16(blk.mlp.fc2.weight), x1, N, bias=blk.mlp.fc2.bias, rowscale=s2, rows_per_group=N,
+            x2, nn1, nm1, nr1 = ops.rowgemm_resid_ln(g, store.w16(blk.mlp.fc2.weight), x1, rpt, bias=blk.mlp.fc2.bias, rowscale=s2, rows_per_group=N,
                                                      ln_w=nxt.norm1.weight if nxt is not None else None, ln_b=nxt.norm1.bias if nxt is not None else None,
                                                      eps=LN_EPS, colscale=blk.gamma_2, aux_out=raw2)
             pre = (nn1, nm1, nr1) if nxt is not None else None

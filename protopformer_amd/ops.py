@@ -80,6 +80,28 @@ def rowgemm_ok(D, K, rows_per_tile):
     return os.environ.get("PPF_ROWGEMM", "1") != "0" and bool(_lib.lib().ppf_rowgemm_supported(int(D), int(K), int(rows_per_tile)))
 
 
+_CU_COUNT = {}
+
+
+def rowgemm_tile_rows(M, rows_per_sample, device=None, backward=False):
+    """Tile height for the full-row GEMMs: one sample per workgroup, or half a sample when whole samples would leave a third of the CUs
+    without a workgroup (batch 128 on 256 CUs: 128 tiles of 197 rows -> 255 tiles of 99).  Tiles need not end on sample boundaries: every
+    epilogue is row-wise and the DropPath scale is indexed by the global row (rows_per_group).
+    Backward keeps whole samples: there the CUs these one-per-CU workgroups leave free run the side stream's weight-gradient GEMMs
+    (measured, deit_tiny batch 128: half-sample tiles in backward -2 %, in forward +1..3 %; PPF_ROWGEMM_SPLIT=0 / 2 = never / both)."""
+    mode = os.environ.get("PPF_ROWGEMM_SPLIT", "1")
+    if mode == "0" or (backward and mode != "2"):
+        return rows_per_sample
+    dev = torch.cuda.current_device() if device is None else device
+    cus = _CU_COUNT.get(dev)
+    if cus is None:
+        cus = _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    tiles = (M + rows_per_sample - 1) // rows_per_sample
+    if 3 * tiles <= 2 * cus and rows_per_sample > 16:
+        return (rows_per_sample + 1) // 2
+    return rows_per_sample
+
+
 def rowgemm_bf16(a, b, rows_per_tile, bias=None):
     """bf16 [M, D] = a [M, K] @ b [D, K]^T (+ bias)."""
     _chk(a, torch.bfloat16), _chk(b, torch.bfloat16)

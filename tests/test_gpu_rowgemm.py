@@ -34,7 +34,8 @@ def test_rowgemm_bf16_and_transposed_shadow(M, D, K, rpt):
                                                           (5 * 82, 384, 1536, 82, False, False), (2 * 196, 192, 768, 196, True, False),
                                                           (3 * 197, 192, 192, 197, True, False), (3 * 196, 192, 192, 196, True, True),
                                                           (2 * 196, 192, 768, 196, False, True)])
-def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln, layerscale):
+@pytest.mark.parametrize("half_tiles", [False, True], ids=["sample-tiles", "half-sample-tiles"])
+def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln, layerscale, half_tiles):
     """layerscale: CaiT's per-channel gamma on the branch (cait:153-155) and the unscaled branch as a second (bf16) output."""
     from protopformer_amd import ops
     a, b, g = _mk(M, D, K, 2)
@@ -47,7 +48,10 @@ def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln, layerscale):
     branch = a.float() @ b.float().t() + bias
     x_ref = res + scale.repeat_interleave(rpt)[:, None] * (branch * gamma if layerscale else branch)
     raw = torch.empty((M, D), dtype=torch.bfloat16, device="cuda") if layerscale else None
-    xo, n, mean, rstd = ops.rowgemm_resid_ln(a.cuda(), b.cuda(), res.cuda(), rpt, bias=bias.cuda(), rowscale=scale.cuda(), rows_per_group=rpt,
+    # half_tiles: workgroup tiles of half a sample that do not end on sample boundaries (ops.rowgemm_tile_rows at small batches); the
+    # DropPath factor stays per SAMPLE (rows_per_group)
+    tile = (rpt + 1) // 2 if half_tiles else rpt
+    xo, n, mean, rstd = ops.rowgemm_resid_ln(a.cuda(), b.cuda(), res.cuda(), tile, bias=bias.cuda(), rowscale=scale.cuda(), rows_per_group=rpt,
                                              ln_w=lw.cuda() if with_ln else None, ln_b=lb.cuda() if with_ln else None,
                                              colscale=gamma.cuda() if layerscale else None, aux_out=raw)
     torch.cuda.synchronize()
@@ -68,7 +72,8 @@ def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln, layerscale):
 
 @pytest.mark.parametrize("M,D,K,rpt", [(4 * 197, 384, 1536, 197), (3 * 197, 384, 1152, 197), (5 * 82, 384, 1536, 82), (2 * 196, 192, 768, 196),
                                        (3 * 197, 192, 576, 197)])
-def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt):
+@pytest.mark.parametrize("half_tiles", [False, True], ids=["sample-tiles", "half-sample-tiles"])
+def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt, half_tiles):
     """dn = dy W (W^T passed contraction-contiguous) -> LayerNorm backward + residual gradient, against torch.autograd on
     y = LN(x) * w + b, L = sum(dn * y) + sum(dres * x)."""
     from protopformer_amd import ops
@@ -87,7 +92,8 @@ def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt):
     mean, rstd = mu.cuda(), (var + 1e-6).rsqrt().cuda()
     dw = torch.full((D,), 0.5, device="cuda"); db = torch.full((D,), -0.25, device="cuda")           # accumulate (+=) semantics
     cast = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
-    dx = ops.rowgemm_lnbwd(a.cuda(), b.cuda(), x.cuda(), mean, rstd, w.cuda(), dw, db, rpt, dres_in=dres.cuda(), cast_out=cast, rowscale=scale.cuda(),
+    tile = (rpt + 1) // 2 if half_tiles else rpt
+    dx = ops.rowgemm_lnbwd(a.cuda(), b.cuda(), x.cuda(), mean, rstd, w.cuda(), dw, db, tile, dres_in=dres.cuda(), cast_out=cast, rowscale=scale.cuda(),
                            rows_per_group=rpt)
     torch.cuda.synchronize()
     e = dict(dx=rel_err(dx.cpu(), dx_ref), dw=rel_err(dw.cpu() - 0.5, wr.grad), db=rel_err(db.cpu() + 0.25, br.grad),
@@ -97,7 +103,7 @@ def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt):
     # in place on the residual gradient (dx_out aliases dres_in) and bit-identical from run to run
     dres_c = dres.cuda()
     dw2 = torch.full((D,), 0.5, device="cuda"); db2 = torch.full((D,), -0.25, device="cuda")
-    dx2 = ops.rowgemm_lnbwd(a.cuda(), b.cuda(), x.cuda(), mean, rstd, w.cuda(), dw2, db2, rpt, dres_in=dres_c, dx_out=dres_c, cast_out=cast, rowscale=scale.cuda(),
+    dx2 = ops.rowgemm_lnbwd(a.cuda(), b.cuda(), x.cuda(), mean, rstd, w.cuda(), dw2, db2, tile, dres_in=dres_c, dx_out=dres_c, cast_out=cast, rowscale=scale.cuda(),
                             rows_per_group=rpt)
     torch.cuda.synchronize()
     assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(db2, db)
