@@ -93,7 +93,9 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
  *                         dx_out = dres_in + LN'(dn; x, mean, rstd, w) (fp32, may alias dres_in; NULL = 0);
  *                         cast_out = bf16(rowscale[m / rows_per_group] * dx_out) = the gradient entering the residual branch below
  *                         (optional); partial[tiles][2][D] = per-tile column sums (d ln weight, d ln bias), summed in a fixed order
- *                         by ppf_rowgemm_colsum (may run on another stream). */
+ *                         by ppf_rowgemm_colsum (may run on another stream).  colscale != NULL = CaiT's LayerScale on the branch
+ *                         below (cait:153-155): cast_out = bf16(rowscale * colscale[n] * dx_out), branch = the bf16 unscaled branch
+ *                         output saved by ppf_rowgemm_resid_ln's aux_out, partial[tiles][3][D] with d gamma's sums third. */
 int ppf_rowgemm_supported(int D, int K, int rows_per_tile);
 int ppf_rowgemm_bf16(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* bias, void* out,
                      ppf_stream_t stream);
@@ -102,8 +104,8 @@ int ppf_rowgemm_resid_ln(const void* A, const void* B, int M, int D, int K, int 
                          const float* ln_w, const float* ln_b, void* ln_out, float* ln_mean, float* ln_rstd, float eps, ppf_stream_t stream);
 int ppf_rowgemm_lnbwd(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* x, const float* mean,
                       const float* rstd, const float* w, const float* dres_in, float* dx_out, void* cast_out, const float* rowscale,
-                      int rows_per_group, float* partial, size_t partial_bytes, ppf_stream_t stream);
-int ppf_rowgemm_colsum(const float* partial, int tiles, int D, float* dw, float* db, ppf_stream_t stream);
+                      int rows_per_group, const float* colscale, const void* branch, float* partial, size_t partial_bytes, ppf_stream_t stream);
+int ppf_rowgemm_colsum(const float* partial, int tiles, int D, int nparts, float* dw, float* db, float* dg, ppf_stream_t stream);
 /* Transposed bf16 copies of n weight matrices in one launch (the input-gradient products read W^T contraction-contiguous):
  * desc (device, int64 [n][4]) = (source element offset, destination element offset, rows, cols) into src / dst; dst[c][r] = src[r][c].
  * total_tiles = sum over the matrices of ceil(rows / 64) * ceil(cols / 64). */

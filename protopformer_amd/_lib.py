@@ -15,8 +15,8 @@ SIGS = {
     "ppf_device_info": "pppi",
     "ppf_rowgemm_bf16": "pp" "iiiiii" "pp" "s",
     "ppf_rowgemm_resid_ln": "pp" "iiiiii" "p" "pp" "pi" "pp" "pp" "ppp" "f" "s",
-    "ppf_rowgemm_lnbwd": "pp" "iiiiii" "pppp" "ppp" "pi" "pz" "s",
-    "ppf_rowgemm_colsum": "p" "ii" "pp" "s",
+    "ppf_rowgemm_lnbwd": "pp" "iiiiii" "pppp" "ppp" "pi" "pp" "pz" "s",
+    "ppf_rowgemm_colsum": "p" "iii" "ppp" "s",
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",
     "ppf_gemm_probe_read": "pppp",

@@ -262,11 +262,15 @@ def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
     return dqkv
 
 
-def _mlp_bwd(store, blk, L, dyb):
-    """Shared MLP backward: consumes dyb = bf16 gradient of the fc2 output; returns dn2 bf16."""
-    _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight)
+def _mlp_bwd(store, blk, L, dyb, fc2_bias=False, want_dn=True):
+    """Shared MLP backward: consumes dyb = bf16 gradient of the fc2 output; returns dn2 bf16 (want_dn) or dh, the gradient at fc1's
+    output (the caller then fuses fc1's input gradient with the LayerNorm backward).  fc2_bias: dyb's producer did not accumulate
+    fc2.bias' gradient, the weight-gradient GEMM that reads dyb anyway sums its columns."""
+    _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias if fc2_bias else None)
     dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
     _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+    if not want_dn:
+        return dh
     return ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
 
 
@@ -330,26 +334,52 @@ def cait_backward(ppnet, store, saved, df):
     lnb(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
                       colscale=last.gamma_2, dbias_next=gv(last.mlp.fc2.bias), branch=sa[-1]["raw2"], dcolscale=gv(last.gamma_2))
     gs = getattr(ppnet, "_grad_sync", None)
+    # Input gradient of fc1 / qkv + LayerNorm backward + LayerScale terms of the branch below as one full-row kernel (csrc/rowgemm.hip,
+    # RG_LNBWD_LS) where the shape is covered.  Whole samples per workgroup: B = 128 leaves half the CUs to the side stream's weight gradients.
+    rptb = ops.rowgemm_tile_rows(M, N, backward=True)
+    hid = feats.blocks[0].mlp.fc1.out_features if len(feats.blocks) else 0
+    rowb = (os.environ.get("PPF_CAIT_ROW_BWD", "1") != "0" and len(sa) > 0 and store.w16t(feats.blocks[0].mlp.fc1.weight) is not None
+            and ops.rowgemm_ok(D, hid, rptb) and ops.rowgemm_ok(D, 3 * D, rptb) and ops.rowgemm_ok(D, D, rptb))
+    bias_done = True                       # the producer of the current dyb has already accumulated the bias gradient of the Linear above it
     for i in range(len(sa) - 1, -1, -1):
         L, blk = sa[i], feats.blocks[i]
-        dn2 = _mlp_bwd(store, blk, L, dyb)
-        lane.before_overwrite(dyb)
-        lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
-                          cast_out=dyb, rowscale=L["s1"], rows_per_group=N, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias),
-                          branch=L["raw1"], dcolscale=gv(blk.gamma_1))
-        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
-        dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
+        if rowb:
+            dh = _mlp_bwd(store, blk, L, dyb, fc2_bias=not bias_done, want_dn=False)
+            lane.before_overwrite(dyb)
+            ops.rowgemm_lnbwd(dh, store.w16t(blk.mlp.fc1.weight), L["x1"], L["mean2"], L["rstd2"], blk.norm2.weight, gv(blk.norm2.weight), gv(blk.norm2.bias),
+                              rptb, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=N, lane=lane, defer_reduce=True,
+                              colscale=blk.gamma_1, branch=L["raw1"], dcolscale=gv(blk.gamma_1))
+            _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, blk.attn.proj.bias)
+            dao = ops.rowgemm_bf16(dyb, store.w16t(blk.attn.proj.weight), rptb)
+        else:
+            dn2 = _mlp_bwd(store, blk, L, dyb, fc2_bias=not bias_done)
+            lane.before_overwrite(dyb)
+            lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
+                              cast_out=dyb, rowscale=L["s1"], rows_per_group=N, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias),
+                              branch=L["raw1"], dcolscale=gv(blk.gamma_1))
+            _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
+            dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
         dqkv = _th_attention_bwd(store, blk, L, dao, B, H, N, D)
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
-        dn1 = ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
+        dn1 = None if rowb else ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
         if i > 0:
             prev, Lp = feats.blocks[i - 1], sa[i - 1]
             lane.before_overwrite(dyb)
-            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx,
-                              dx_out=dx, cast_out=dyb, rowscale=Lp["s2"], rows_per_group=N, colscale=prev.gamma_2,
-                              dbias_next=gv(prev.mlp.fc2.bias), branch=Lp["raw2"], dcolscale=gv(prev.gamma_2))
+            if rowb:
+                ops.rowgemm_lnbwd(dqkv, store.w16t(blk.attn.qkv.weight), L["x"], L["mean1"], L["rstd1"], blk.norm1.weight, gv(blk.norm1.weight), gv(blk.norm1.bias),
+                                  rptb, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=Lp["s2"], rows_per_group=N, lane=lane, defer_reduce=True,
+                                  colscale=prev.gamma_2, branch=Lp["raw2"], dcolscale=gv(prev.gamma_2))
+            else:
+                lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx,
+                                  dx_out=dx, cast_out=dyb, rowscale=Lp["s2"], rows_per_group=N, colscale=prev.gamma_2,
+                                  dbias_next=gv(prev.mlp.fc2.bias), branch=Lp["raw2"], dcolscale=gv(prev.gamma_2))
+            bias_done = not rowb
         else:
-            lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
+            if rowb:
+                ops.rowgemm_lnbwd(dqkv, store.w16t(blk.attn.qkv.weight), L["x"], L["mean1"], L["rstd1"], blk.norm1.weight, gv(blk.norm1.weight), gv(blk.norm1.bias),
+                                  rptb, dres_in=dx, dx_out=dx, lane=lane, defer_reduce=True)
+            else:
+                lnb(dn1, L["x"], blk.norm1.weight, L["mean1"], L["rstd1"], gv(blk.norm1.weight), gv(blk.norm1.bias), dres_in=dx, dx_out=dx)
         if gs is not None and i in gs.block_chunk:
             lane.flush()
             _lib.run_live(lambda c=gs.block_chunk[i]: gs.chunk_ready(c, also=lane.streams))
@@ -364,4 +394,9 @@ def cait_backward(ppnet, store, saved, df):
     lane.join()
 
 
-CAIT_FNS = dict(embed=cait_embed, blocks=cait_blocks_fwd, backward=cait_backward)
+def cait_t16_params(feats):
+    """Weights whose input-gradient products read W^T contraction-contiguous (csrc/rowgemm.hip): fc1, qkv, proj of the talking-heads blocks."""
+    return [w for blk in feats.blocks for w in (blk.mlp.fc1.weight, blk.attn.qkv.weight, blk.attn.proj.weight)]
+
+
+CAIT_FNS = dict(embed=cait_embed, blocks=cait_blocks_fwd, backward=cait_backward, t16_params=cait_t16_params)

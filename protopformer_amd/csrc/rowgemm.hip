@@ -42,7 +42,7 @@ constexpr int RG_BK = 64, RG_S = 2, RG_NTHR = 512;                  // k per sta
 #ifndef RG_ISSUE_FRAC
 #define RG_ISSUE_FRAC 100                                            // percent of a stage's MFMA stream over which a wave issues its pieces
 #endif
-enum RgEpi { RG_BF16 = 0, RG_RESID_LN = 1, RG_LNBWD = 2 };
+enum RgEpi { RG_BF16 = 0, RG_RESID_LN = 1, RG_LNBWD = 2, RG_LNBWD_LS = 3 };
 
 typedef __attribute__((address_space(3))) void rg_lds_t;
 typedef const __attribute__((address_space(1))) void rg_gbl_t;
@@ -59,8 +59,10 @@ struct RowGemmParams {
     const float* ln_w; const float* ln_b; bf16_t* ln_out; float* ln_mean; float* ln_rstd; float eps;
     // RG_LNBWD: dn = acc (+ bias); dx_out = dres_in + LN'(dn; x, mean, rstd, w);  cast_out = bf16(rowscale * dx_out);
     //           partial[tile][0][n] = sum_m dn * xhat (d ln weight), partial[tile][1][n] = sum_m dn (d ln bias)
+    // RG_LNBWD_LS (CaiT LayerScale below the residual, cait:153-155): cast_out = bf16(rowscale * colscale[n] * dx_out) and
+    //           partial[tile][2][n] = sum_m rowscale * dx_out * branch[m][n] (d gamma; branch = the unscaled branch output saved by forward)
     const float* x; const float* mean; const float* rstd; const float* w;
-    const float* dres_in; float* dx_out; bf16_t* cast_out; float* partial;
+    const float* dres_in; float* dx_out; bf16_t* cast_out; float* partial; const bf16_t* branch;
     int no_touch;                  // measurement switch (PPF_ROWGEMM_TOUCH=0): no L2 touch-prefetch
 };
 
@@ -220,25 +222,28 @@ __global__ __launch_bounds__(RG_NTHR, 2) void rowgemm_kernel(const RowGemmParams
     // ---- epilogue -------------------------------------------------------------------------------------------------------------------
     float* img = reinterpret_cast<float*>(smem);                           // [64][LDP] fp32
     float* stash = img + 64 * LDP;                                         // [3][D]: bias | ln_w (or w) | ln_b
-    float* colp = stash + 3 * D;                                           // [8 waves][2][D] column partial sums (RG_LNBWD)
+    constexpr bool LNB = EPI == RG_LNBWD || EPI == RG_LNBWD_LS, LS = EPI == RG_LNBWD_LS;
+    constexpr int NPART = LS ? 3 : 2;                                      // column-sum arrays per tile
+    float* colp = stash + 3 * D;                                           // [8 waves][NPART][D] column partial sums (LayerNorm backward)
     for (int i = tid; i < D; i += RG_NTHR) {
         stash[i] = p.bias ? p.bias[i] : 0.f;
         if constexpr (EPI == RG_RESID_LN) { stash[D + i] = p.ln_out ? p.ln_w[i] : 0.f; stash[2 * D + i] = p.ln_out ? p.ln_b[i] : 0.f; }
-        if constexpr (EPI == RG_LNBWD) stash[D + i] = p.w[i];
+        if constexpr (LNB) stash[D + i] = p.w[i];
+        if constexpr (LS) stash[2 * D + i] = p.colscale[i];
     }
     // LPR lanes per row, each owning the VW-column pieces at VW*jl + (D/3)*i (512-byte fp32 / 256-byte bf16 row segments per access at
     // D = 384).  The LayerNorm backward holds five values per column and two column accumulators: 2 columns per piece (64 lanes per
     // row at D = 384) keeps it inside the 256-register budget next to the accumulators of the chunks still waiting; the others use 4.
-    constexpr int VW = (EPI == RG_LNBWD) ? 2 : 4;                          // columns per piece
+    constexpr int VW = LNB ? 2 : 4;                                        // columns per piece
     constexpr int NSEG = 3, PIECE = D / NSEG, LPR = PIECE / VW, RPW = 64 / LPR;       // pieces per row, columns a row's lanes cover per piece, lanes per row, rows per wave at a time
     static_assert(D % 3 == 0 && (LPR == 16 || LPR == 32 || LPR == 64), "D = 3 x 64 or 3 x 128");
     const int jl = lane % LPR, rsub = lane / LPR;
-    float adw[NSEG][VW], adb[NSEG][VW];
-    if constexpr (EPI == RG_LNBWD) {
+    float adw[NSEG][VW], adb[NSEG][VW], adg[NSEG][VW];
+    if constexpr (LNB) {
 #pragma unroll
         for (int i = 0; i < NSEG; ++i)
 #pragma unroll
-            for (int e = 0; e < VW; ++e) adw[i][e] = adb[i][e] = 0.f;
+            for (int e = 0; e < VW; ++e) adw[i][e] = adb[i][e] = adg[i][e] = 0.f;
     }
     const float invD = 1.0f / (float)D;
     constexpr int NCH = (MTP + 3) / 4;                                     // 64-row chunks
@@ -371,13 +376,21 @@ __global__ __launch_bounds__(RG_NTHR, 2) void rowgemm_kernel(const RowGemmParams
 #pragma unroll
                         for (int e = 0; e < VW; ++e) { dx[e] = dr[i][e] + rs * (gg[i][e] - c1 - xh[i][e] * c2); dc[e] = dx[e] * rsc; }
                         rg_st<VW>(p.dx_out + o, dx);
+                        if constexpr (LS) {
+                            static_assert(VW == 2, "branch is read as one bf16 pair");
+                            const float2 br = unpack_bf16x2(*reinterpret_cast<const uint32_t*>(p.branch + o));
+                            float cs[VW];
+                            rg_ld<VW>(cs, stash + 2 * D + VW * jl + PIECE * i);
+                            adg[i][0] += dc[0] * br.x; adg[i][1] += dc[1] * br.y;
+                            dc[0] *= cs[0]; dc[1] *= cs[1];
+                        }
                         if (p.cast_out) rg_st16<VW>(p.cast_out + o, dc);
                     }
                 }
             }
         }
     }
-    if constexpr (EPI == RG_LNBWD) {
+    if constexpr (LNB) {
         // column sums of this tile in a fixed order: a lane owns its columns for every row its wave handled; then the 8 waves in order
         __syncthreads();                                                   // an early-exit chunk loop leaves no barrier behind the last image reads
 #pragma unroll
@@ -385,36 +398,40 @@ __global__ __launch_bounds__(RG_NTHR, 2) void rowgemm_kernel(const RowGemmParams
 #pragma unroll
             for (int e = 0; e < VW; ++e)
 #pragma unroll
-                for (int o = LPR; o < 64; o <<= 1) { adw[i][e] += __shfl_xor(adw[i][e], o, 64); adb[i][e] += __shfl_xor(adb[i][e], o, 64); }
+                for (int o = LPR; o < 64; o <<= 1) {
+                    adw[i][e] += __shfl_xor(adw[i][e], o, 64); adb[i][e] += __shfl_xor(adb[i][e], o, 64);
+                    if constexpr (LS) adg[i][e] += __shfl_xor(adg[i][e], o, 64);
+                }
         if (lane < LPR) {
 #pragma unroll
             for (int i = 0; i < NSEG; ++i) {
-                rg_st<VW>(colp + (wave * 2 + 0) * D + VW * jl + PIECE * i, adw[i]);
-                rg_st<VW>(colp + (wave * 2 + 1) * D + VW * jl + PIECE * i, adb[i]);
+                rg_st<VW>(colp + (wave * NPART + 0) * D + VW * jl + PIECE * i, adw[i]);
+                rg_st<VW>(colp + (wave * NPART + 1) * D + VW * jl + PIECE * i, adb[i]);
+                if constexpr (LS) rg_st<VW>(colp + (wave * NPART + 2) * D + VW * jl + PIECE * i, adg[i]);
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * D; i += RG_NTHR) {
+        for (int i = tid; i < NPART * D; i += RG_NTHR) {
             float s = 0.f;
 #pragma unroll
-            for (int w_ = 0; w_ < 8; ++w_) s += colp[w_ * 2 * D + i];
-            p.partial[(size_t)blockIdx.x * 2 * D + i] = s;
+            for (int w_ = 0; w_ < 8; ++w_) s += colp[w_ * NPART * D + i];
+            p.partial[(size_t)blockIdx.x * NPART * D + i] = s;
         }
     }
 }
 
 // dst[c] += sum over tiles of partial[tile][which][c], fixed order (one 1024-thread workgroup per 64 columns and array; 16 lane groups
 // each add every 16th tile, the 16 group sums are added in order through LDS)
-__global__ __launch_bounds__(1024) void rowgemm_colsum_kernel(const float* __restrict__ partial, int ntiles, int D, float* d0, float* d1) {
+__global__ __launch_bounds__(1024) void rowgemm_colsum_kernel(const float* __restrict__ partial, int ntiles, int D, int nparts, float* d0, float* d1, float* d2) {
     __shared__ float red[16][64];
     const int which = blockIdx.y;
-    float* dst = which == 0 ? d0 : d1;
+    float* dst = which == 0 ? d0 : which == 1 ? d1 : d2;
     if (!dst) return;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (c < D) {
 #pragma unroll 8
-        for (int b = g; b < ntiles; b += 16) s += partial[((size_t)b * 2 + which) * D + c];
+        for (int b = g; b < ntiles; b += 16) s += partial[((size_t)b * nparts + which) * D + c];
     }
     red[g][cl] = s;
     __syncthreads();
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(1024) void rowgemm_colsum_kernel(const float* __res
 template <int D, int MT>
 constexpr int rg_lds_bytes() {
     constexpr int WN = D / 48, WM = 8 / WN, MTW = (MT + WM - 1) / WM, MTP = MTW * WM;
-    constexpr int ring = RG_S * (MTP * 16 * 128 + D * 128), epi = 64 * (D + 4) * 4 + 3 * D * 4 + 8 * 2 * D * 4;
+    constexpr int ring = RG_S * (MTP * 16 * 128 + D * 128), epi = 64 * (D + 4) * 4 + 3 * D * 4 + 8 * 3 * D * 4;
     return ring > epi ? ring : epi;
 }
 
@@ -455,6 +472,7 @@ int rg_dispatch_epi(const RowGemmParams& p, int epi, int tiles, hipStream_t stre
         case RG_BF16: return rg_launch<D, MT, RG_BF16>(p, tiles, stream);
         case RG_RESID_LN: return rg_launch<D, MT, RG_RESID_LN>(p, tiles, stream);
         case RG_LNBWD: return rg_launch<D, MT, RG_LNBWD>(p, tiles, stream);
+        case RG_LNBWD_LS: return rg_launch<D, MT, RG_LNBWD_LS>(p, tiles, stream);
         default: break;
     }
     ppf_set_error("ppf_rowgemm: unknown epilogue %d", epi);
@@ -514,25 +532,31 @@ int ppf_rowgemm_resid_ln(const void* A, const void* B, int M, int D, int K, int 
 // (autograd of deit:76-81): dn = A B^T;  dx_out = dres_in + LN'(dn; x, mean, rstd, w) (fp32, may alias dres_in; dres_in == NULL: 0);
 // cast_out = bf16(rowscale[m / rows_per_group] * dx_out) (the gradient entering the residual branch below, optional);
 // partial[tiles][2][D] receives this call's per-tile column sums (d ln weight, d ln bias): add them up with ppf_rowgemm_colsum.
+// colscale != NULL (CaiT LayerScale, cait:153-155; then branch = the bf16 unscaled branch output of the forward pass and cast_out are
+// required): cast_out = bf16(rowscale * colscale[n] * dx_out) and partial is [tiles][3][D], the third array = d gamma's per-tile sums.
 int ppf_rowgemm_lnbwd(const void* A, const void* B, int M, int D, int K, int lda, int ldb, int rows_per_tile, const float* x, const float* mean,
                       const float* rstd, const float* w, const float* dres_in, float* dx_out, void* cast_out, const float* rowscale,
-                      int rows_per_group, float* partial, size_t partial_bytes, hipStream_t stream) {
+                      int rows_per_group, const float* colscale, const void* branch, float* partial, size_t partial_bytes, hipStream_t stream) {
     PPF_CHECK_ARG(A && B && x && mean && rstd && w && dx_out && partial, PPF_ERR_ARG, "ppf_rowgemm_lnbwd: null pointer");
     PPF_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)dres_in) | ((uintptr_t)dx_out) | ((uintptr_t)cast_out)) & 15) == 0, PPF_ERR_ALIGN, "ppf_rowgemm_lnbwd: misaligned pointer");
     const int tiles = rows_per_tile > 0 ? (M + rows_per_tile - 1) / rows_per_tile : 0;
-    PPF_CHECK_ARG(partial_bytes >= (size_t)tiles * 2 * D * sizeof(float), PPF_ERR_ARG, "ppf_rowgemm_lnbwd: partial needs tiles*2*D*4 = %zu bytes",
-                  (size_t)tiles * 2 * D * sizeof(float));
+    const int nparts = colscale ? 3 : 2;
+    PPF_CHECK_ARG(partial_bytes >= (size_t)tiles * nparts * D * sizeof(float), PPF_ERR_ARG, "ppf_rowgemm_lnbwd: partial needs tiles*%d*D*4 = %zu bytes",
+                  nparts, (size_t)tiles * nparts * D * sizeof(float));
+    PPF_CHECK_ARG(colscale == nullptr || (branch && cast_out && (((uintptr_t)branch) & 15) == 0), PPF_ERR_ARG,
+                  "ppf_rowgemm_lnbwd: LayerScale needs the saved branch and cast_out");
     RowGemmParams p = {};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.K = K; p.lda = lda; p.ldb = ldb; p.rows_per_tile = rows_per_tile;
     p.x = x; p.mean = mean; p.rstd = rstd; p.w = w; p.dres_in = dres_in; p.dx_out = dx_out; p.cast_out = (bf16_t*)cast_out; p.rowscale = rowscale;
-    p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.partial = partial;
-    return rg_run(p, D, RG_LNBWD, stream);
+    p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1; p.partial = partial; p.colscale = colscale; p.branch = (const bf16_t*)branch;
+    return rg_run(p, D, colscale ? RG_LNBWD_LS : RG_LNBWD, stream);
 }
 
-// dw[c] += sum_tiles partial[t][0][c], db[c] += sum_tiles partial[t][1][c] in a fixed order (may run on another stream)
-int ppf_rowgemm_colsum(const float* partial, int tiles, int D, float* dw, float* db, hipStream_t stream) {
-    PPF_CHECK_ARG(partial && tiles > 0 && D > 0, PPF_ERR_ARG, "ppf_rowgemm_colsum: bad arguments");
-    hipLaunchKernelGGL(rowgemm_colsum_kernel, dim3((D + 63) / 64, 2), dim3(1024), 0, stream, partial, tiles, D, dw, db);
+// dw[c] += sum_tiles partial[t][0][c], db[c] += sum_tiles partial[t][1][c] (and, nparts = 3, dg[c] += sum_tiles partial[t][2][c]) in a
+// fixed order (may run on another stream); a NULL destination skips its array
+int ppf_rowgemm_colsum(const float* partial, int tiles, int D, int nparts, float* dw, float* db, float* dg, hipStream_t stream) {
+    PPF_CHECK_ARG(partial && tiles > 0 && D > 0 && (nparts == 2 || nparts == 3), PPF_ERR_ARG, "ppf_rowgemm_colsum: bad arguments");
+    hipLaunchKernelGGL(rowgemm_colsum_kernel, dim3((D + 63) / 64, nparts), dim3(1024), 0, stream, partial, tiles, D, nparts, dw, db, dg);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -131,20 +131,22 @@ def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_pe
 
 
 def rowgemm_lnbwd(a, b, x, mean, rstd, w, dw, db, rows_per_tile, dres_in=None, dx_out=None, cast_out=None, rowscale=None, rows_per_group=1,
-                  lane=None, defer_reduce=False):
+                  lane=None, defer_reduce=False, colscale=None, branch=None, dcolscale=None):
     """dn = a @ b^T is the gradient w.r.t. the output of LN(x); dx_out = dres_in + LN'(dn) (fp32), cast_out = bf16(rowscale * dx_out);
     dw / db (the LayerNorm's parameter gradients) += the column sums, reduced in a fixed order by a second small kernel (on `lane`,
-    the side stream, when given)."""
+    the side stream, when given).  colscale / branch / dcolscale: CaiT's LayerScale on the branch below (cast_out additionally times
+    colscale, dcolscale += sum_m rowscale * dx_out * branch)."""
     _chk(a, torch.bfloat16), _chk(b, torch.bfloat16), _chk(x, torch.float32)
     M, K = a.shape
     D = b.shape[0]
     tiles = (M + rows_per_tile - 1) // rows_per_tile
-    part = torch.empty(tiles * 2 * D, dtype=torch.float32, device=a.device)
+    nparts = 3 if colscale is not None else 2
+    part = torch.empty(tiles * nparts * D, dtype=torch.float32, device=a.device)
     if dx_out is None:
         dx_out = torch.empty((M, D), dtype=torch.float32, device=a.device)
     _lib.call("ppf_rowgemm_lnbwd", a, b, M, D, K, K, b.shape[1], rows_per_tile, x, mean, rstd, w, dres_in, dx_out, cast_out, rowscale, rows_per_group,
-              part, part.numel() * 4)
-    red = lambda: _lib.call("ppf_rowgemm_colsum", part, tiles, D, dw, db)
+              colscale, branch, part, part.numel() * 4)
+    red = lambda: _lib.call("ppf_rowgemm_colsum", part, tiles, D, nparts, dw, db, dcolscale)
     if lane is not None:
         lane.submit(red, (part,), defer=defer_reduce)
     else:

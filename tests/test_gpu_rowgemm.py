@@ -73,7 +73,8 @@ def test_rowgemm_resid_ln_vs_torch(M, D, K, rpt, with_ln, layerscale, half_tiles
 @pytest.mark.parametrize("M,D,K,rpt", [(4 * 197, 384, 1536, 197), (3 * 197, 384, 1152, 197), (5 * 82, 384, 1536, 82), (2 * 196, 192, 768, 196),
                                        (3 * 197, 192, 576, 197)])
 @pytest.mark.parametrize("half_tiles", [False, True], ids=["sample-tiles", "half-sample-tiles"])
-def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt, half_tiles):
+@pytest.mark.parametrize("layerscale", [False, True], ids=["plain", "layerscale"])
+def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt, half_tiles, layerscale):
     """dn = dy W (W^T passed contraction-contiguous) -> LayerNorm backward + residual gradient, against torch.autograd on
     y = LN(x) * w + b, L = sum(dn * y) + sum(dres * x)."""
     from protopformer_amd import ops
@@ -93,20 +94,32 @@ def test_rowgemm_lnbwd_vs_autograd(M, D, K, rpt, half_tiles):
     dw = torch.full((D,), 0.5, device="cuda"); db = torch.full((D,), -0.25, device="cuda")           # accumulate (+=) semantics
     cast = torch.empty((M, D), dtype=torch.bfloat16, device="cuda")
     tile = (rpt + 1) // 2 if half_tiles else rpt
+    # layerscale (cait:153-155): the branch below the residual is gamma * branch: cast_out carries gamma, d gamma = sum_m scale * dx * branch
+    gamma = (0.5 + torch.rand(D, generator=g)) if layerscale else None
+    branch = torch.randn(M, D, generator=g).bfloat16() if layerscale else None
+    dg = torch.full((D,), 0.125, device="cuda") if layerscale else None
+    ls = dict(colscale=gamma.cuda(), branch=branch.cuda(), dcolscale=dg) if layerscale else {}
     dx = ops.rowgemm_lnbwd(a.cuda(), b.cuda(), x.cuda(), mean, rstd, w.cuda(), dw, db, tile, dres_in=dres.cuda(), cast_out=cast, rowscale=scale.cuda(),
-                           rows_per_group=rpt)
+                           rows_per_group=rpt, **ls)
     torch.cuda.synchronize()
+    rows_scale = scale.repeat_interleave(rpt)[:, None]
     e = dict(dx=rel_err(dx.cpu(), dx_ref), dw=rel_err(dw.cpu() - 0.5, wr.grad), db=rel_err(db.cpu() + 0.25, br.grad),
-             cast=rel_err(cast.float().cpu(), dx_ref * scale.repeat_interleave(rpt)[:, None]))
-    report(f"rowgemm_lnbwd[{M},{D},{K}]", **e)
+             cast=rel_err(cast.float().cpu(), dx_ref * rows_scale * (gamma if layerscale else 1.0)))
+    if layerscale:
+        e["dgamma"] = rel_err(dg.cpu() - 0.125, (dx_ref * rows_scale * branch.float()).sum(0))
+        assert e["dgamma"] < 1e-3
+    report(f"rowgemm_lnbwd[{M},{D},{K}{',ls' if layerscale else ''}]", **e)
     assert e["dx"] < 1e-3 and e["dw"] < 1e-3 and e["db"] < 1e-3 and e["cast"] < 4e-3
     # in place on the residual gradient (dx_out aliases dres_in) and bit-identical from run to run
     dres_c = dres.cuda()
     dw2 = torch.full((D,), 0.5, device="cuda"); db2 = torch.full((D,), -0.25, device="cuda")
+    if layerscale:
+        ls["dcolscale"] = torch.full((D,), 0.125, device="cuda")
     dx2 = ops.rowgemm_lnbwd(a.cuda(), b.cuda(), x.cuda(), mean, rstd, w.cuda(), dw2, db2, tile, dres_in=dres_c, dx_out=dres_c, cast_out=cast, rowscale=scale.cuda(),
-                            rows_per_group=rpt)
+                            rows_per_group=rpt, **ls)
     torch.cuda.synchronize()
     assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(db2, db)
+    assert not layerscale or torch.equal(ls["dcolscale"], dg)
 
 
 def test_transposed_weight_shadow():
