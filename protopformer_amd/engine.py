@@ -452,6 +452,9 @@ class GraphedTrainStep:
             if self.calls <= self.warmup:
                 return train_one_step(self.model, self.criterion, samples, targets, opt, **self.kw)
             self._capture(samples, targets)
+        if samples.shape != self.static_in[0].shape or targets.shape != self.static_in[1].shape or samples.dtype != self.static_in[0].dtype:
+            # a batch the list was not recorded for (a short last batch): the eager step, same kernels and streams, nothing recorded
+            return train_one_step(self.model, self.criterion, samples, targets, opt, **self.kw)
         if samples.data_ptr() != self.static_in[0].data_ptr():
             self.static_in[0].copy_(samples, non_blocking=True)
         if targets.data_ptr() != self.static_in[1].data_ptr():
@@ -487,6 +490,9 @@ class ReplayedTrainStep(GraphedTrainStep):
             finally:
                 self.rec = _lib.stop_recording()
             return self.out
+        if samples.shape != self.static_in[0].shape or targets.shape != self.static_in[1].shape or samples.dtype != self.static_in[0].dtype:
+            # a batch the list was not recorded for (a short last batch): the eager step, same kernels and streams, nothing recorded
+            return train_one_step(self.model, self.criterion, samples, targets, opt, **self.kw)
         if samples.data_ptr() != self.static_in[0].data_ptr():
             self.static_in[0].copy_(samples, non_blocking=True)
         if targets.data_ptr() != self.static_in[1].data_ptr():

@@ -349,24 +349,16 @@ def test_replayed_step_equals_eager_step(arch):
         lb.append(float(rs(x, y)[0]))
     torch.cuda.synchronize()
     assert rs.rec is not None and len(rs.rec.cmds) > 100
-    if arch == "deit":
-        assert la == lb, (la, lb)
-        assert torch.equal(a.flat_store().params, b.flat_store().params) and torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.ema, opt_b.ema)
-    else:
-        # CaiT: the proj_l / proj_w gradients are summed with fp32 atomics (cait.hip); the replay changes launch timing and with it the
-        # summation order, and AdamW's first steps (lr * g / (|g| + eps)) amplify that noise (two EAGER runs differ the same way):
-        # the losses agree to the atomics' spread (measured 1.4e-3 on this tiny batch)
-        assert max(abs(p - q) / abs(p) for p, q in zip(la, lb)) < 5e-3, (la, lb)
-        # ... and ONE replayed step from an identical state reproduces the eager step's gradient to the atomics' noise level
-        a.load_state_dict(b.state_dict()); a.flat_store().invalidate()
-        opt_a.exp_avg.copy_(opt_b.exp_avg); opt_a.exp_avg_sq.copy_(opt_b.exp_avg_sq); opt_a.ema.copy_(opt_b.ema)
-        for grp in opt_a.param_groups + opt_b.param_groups:
-            grp["lr"] = 0.0                                                          # keep the two states identical through the step
-        x, y = batches[1]
-        train_one_step(a, crit, x, y, opt_a, epoch=20, max_norm=1.0)
-        rs(x, y)
-        torch.cuda.synchronize()
-        ga, gb = a.flat_store().grads, b.flat_store().grads
-        assert float((ga - gb).abs().max() / ga.abs().max()) < 1e-4, float((ga - gb).abs().max() / ga.abs().max())
-        opt_a.step_count = opt_b.step_count = 6
-    assert opt_a.step_count == opt_b.step_count == 6
+    # bit-identical for both backbones: every reduction of the step has a fixed order (CaiT's proj_l / proj_w gradients were fp32 atomics
+    # until the fused talking-heads kernels of round 3 replaced them by per-workgroup partial rows + an ordered sum)
+    assert la == lb, (la, lb)
+    assert torch.equal(a.flat_store().params, b.flat_store().params) and torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.ema, opt_b.ema)
+    # a batch of another size (the short last batch of an epoch) runs eagerly on the same state and leaves the recorded list usable
+    xs, ys = batches[0][0][:4].contiguous(), batches[0][1][:4].contiguous()
+    l_a = float(train_one_step(a, crit, xs, ys, opt_a, epoch=20, max_norm=1.0)[0]); l_b = float(rs(xs, ys)[0])
+    x, y = batches[1]
+    l_a2 = float(train_one_step(a, crit, x, y, opt_a, epoch=20, max_norm=1.0)[0]); l_b2 = float(rs(x, y)[0])
+    torch.cuda.synchronize()
+    assert math.isfinite(l_b) and math.isfinite(l_b2) and opt_a.step_count == opt_b.step_count == 8
+    if arch == "cait":                            # DropPath off: the interleaved eager / replayed steps see the same (no) draws
+        assert l_a == l_b and l_a2 == l_b2 and torch.equal(a.flat_store().params, b.flat_store().params)
