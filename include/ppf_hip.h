@@ -137,6 +137,11 @@ int ppf_layernorm_bwd_reduce(const float* partial, int rows, int D, float* dw, f
  * rollout) pass the original token count so that the kept entries equal the masked full-length computation. */
 int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, int B, int H, int N, int D,
                  int self_keep, int eps_n, ppf_stream_t stream);
+/* forward pass + head-mean map in ONE launch (16-row tiles: Q.K^T is computed once, N = 197 runs as 13 x 16 = 208 rows): headmean may be
+ * NULL (no map).  ppf_attn_fwd_hm_supported: 1 for head_dim 64 and N <= 208, else use ppf_attn_fwd + ppf_attn_headmean. */
+int ppf_attn_fwd_hm_supported(int H, int N, int D);
+int ppf_attn_fwd_hm(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, float* headmean, int NP, int B, int H, int N,
+                    int D, int self_keep, int eps_n, ppf_stream_t stream);
 int ppf_attn_headmean(const void* qkv, const float* policy, const float* rowmax, const float* zinv, float* headmean, int NP,
                       int B, int H, int N, int D, int self_keep, int eps_n, ppf_stream_t stream);
 int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv, const float* policy, const float* rowmax,

@@ -29,6 +29,7 @@ SIGS = {
     "ppf_assemble_tokens_bwd": "ppppiiiis",
     "ppf_adamw_step": "pppppp" "li" "ppp" "fff" "i" "ff" "s",
     "ppf_attn_fwd": "ppppp" "iiiii" "i" "s",
+    "ppf_attn_fwd_hm": "pppppp" "i" "iiiii" "i" "s",
     "ppf_attn_headmean": "ppppp" "i" "iiiii" "i" "s",
     "ppf_attn_bwd": "pppppppp" "iiiii" "i" "s",
     "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "pppp" "s",
@@ -113,6 +114,8 @@ def lib():
         _lib.ppf_clip_grad_blocks.argtypes = []
         _lib.ppf_rowgemm_supported.restype = ctypes.c_int
         _lib.ppf_rowgemm_supported.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_attn_fwd_hm_supported.restype = ctypes.c_int
+        _lib.ppf_attn_fwd_hm_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_th_fused_supported.restype = ctypes.c_int
         _lib.ppf_th_fused_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_th_bwd_partial_floats.restype = ctypes.c_size_t

@@ -122,12 +122,13 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         pre = None
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
-        ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, Nc, D, policy=policy, self_keep=True, eps_n=eps_n)
+        # the head-mean map of a layer in front of the reservation (the rollout's input) comes out of the attention launch itself where the
+        # one-launch kernel covers the shape; otherwise it is recomputed from the saved statistics on the side stream
+        hm_fused = i < reserve_layer and "headmean" not in _KO and ops.attn_fwd_hm_ok(H, Nc, D)
+        ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, Nc, D, policy=policy, self_keep=True, eps_n=eps_n, headmean=hm[i] if hm_fused else None)
         if i < reserve_layer:
-            # only the rollout at `reserve_layer` consumes the head-mean maps: recompute them on the side stream, under the
-            # rest of this block
-            def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i):
-                if "headmean" not in _KO:
+            def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i, hm_fused=hm_fused):
+                if "headmean" not in _KO and not hm_fused:
                     ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
                 if side_thr and "thr" not in _KO:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path

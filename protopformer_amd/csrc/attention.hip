@@ -218,6 +218,173 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, Geo<NT>::NW == 8 ? 4 : 2) void attn_
     }
 }
 
+// ------------------------------------------------------------------------------------------- forward + head mean, 16-row geometry
+// Round 3: the forward pass and the head-mean map (the rollout's input, deit:104) in ONE launch.  A workgroup of seven waves owns up to
+// 112 queries of one sample and loops over the heads; a wave owns 16 queries and keeps the whole score strip of a head in registers
+// (v_mfma_f32_16x16x32_bf16, swapped operands: a lane = one query, four consecutive keys per 16-key tile -> 4 x NT16 = 52 registers at
+// N = 197), so the softmax is one pass and the probabilities are added to the head-mean accumulators (another 52 registers) on the way to
+// the P.V product.  Q.K^T is computed once (attn_headmean_kernel recomputed it from the saved statistics and re-read q / k: 202 MB per
+// layer), and N = 197 is tiled as 13 x 16 = 208 keys / queries instead of 7 x 32 = 224.  K and V of the current head sit in LDS
+// in one of two buffers (2 x 52 KB) filled by LDS-DMA: head h + 1 lands while head h is multiplied, one barrier per head, one 7-wave
+// workgroup per CU.  V is read transposed (ds_read_b64_tr_b16) with the key order of the packed probability tiles.
+// (A first version staged through registers with two barriers per head: 110-180 us, all of it staging latency.)
+constexpr int F16_WAVES = 7, F16_NTHR = F16_WAVES * 64;       // 7 x 16 = 112 queries per workgroup: N = 197 -> two workgroups per sample (7 + 6 blocks)
+template <int HD, int NT16>
+struct Fwd16 { static constexpr int ROWS = NT16 * 16, BUF = 2 * ROWS * 128, LDS = 2 * BUF + ROWS * 4; };
+
+// A operand of the P.V product: output index d = dbase + (lane & 15); contraction slots 8 (lane >> 4) + j <-> keys kb + 4 (lane >> 4) + j
+// (j < 4) and kb + 16 + 4 (lane >> 4) + (j - 4): the register order of two adjacent 16-key score tiles
+__device__ __forceinline__ bf16x8 frag_tr16(const unsigned char* tile, int kb, int dbase, int lane, bool second) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int s = lane & 15, grp = lane >> 4;
+    const int d = dbase + 4 * (s & 3);
+    const int r0 = kb + 4 * grp + (s >> 2), r1 = r0 + 16;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + row_off(r0, d >> 3) + ((d & 7) << 1)));
+    bf16x4 hi = lo;
+    if (second) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + row_off(r1, d >> 3) + ((d & 7) << 1)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int HD, int NT16, bool POLICY>
+__global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParams p) {
+    static_assert(HD == 64, "128-byte rows");
+    constexpr int KS = HD / 32, DB = HD / 16, ROWS = NT16 * 16, BUF = Fwd16<HD, NT16>::BUF;
+    constexpr int NPIECE = 2 * ROWS / 8, PPW = (NPIECE + F16_WAVES - 1) / F16_WAVES;      // 1 KiB pieces (8 rows) of K then V; pieces per wave
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    float* pol = reinterpret_cast<float*>(lds16 + 2 * BUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.y, N = p.N;
+    // the sample's 16-query blocks are dealt out evenly to the workgroups of this sample (13 blocks on 2 workgroups: 7 + 6)
+    const int nb = (N + 15) / 16, nw = gridDim.x, per = nb / nw, rem = nb % nw, x = blockIdx.x;
+    const int first = x * per + min(x, rem), cnt = per + (x < rem ? 1 : 0);
+    const bool active = wave < cnt;
+    const int q = (first + wave) * 16 + l15, qc = min(q, N - 1);
+    const int qself = p.self_keep ? q : -1;
+    const float c = p.eps_c, c1 = p.scale * LOG2E;
+    // K / V of a head go global -> LDS by LDS-DMA (no staging registers, asynchronous): piece j = wave + 7 i covers rows 8 j' .. 8 j' + 7 of K
+    // (j < ROWS / 8) or V; lane l carries row (l >> 3), LDS chunk slot (l & 7) whose SOURCE chunk is slot ^ kswz(row).  Rows past N repeat
+    // the last valid row (finite; their probabilities are forced to zero below).  Two buffers: head h + 1 lands while head h is multiplied.
+    int src_off[PPW], dst_off[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int j = min(wave + F16_WAVES * i, NPIECE - 1);
+        const int isv = j >= ROWS / 8 ? 1 : 0, r = (j - isv * (ROWS / 8)) * 8 + (lane >> 3);
+        src_off[i] = (min(r, N - 1) * p.ld + (1 + isv) * p.D) * 2 + (((lane & 7) ^ kswz(r)) << 4);
+        dst_off[i] = j * 1024;
+    }
+    const unsigned char* gbase = reinterpret_cast<const unsigned char*>(p.qkv + (size_t)b * N * p.ld);
+    auto issue = [&](int h, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            if (wave + F16_WAVES * i < NPIECE)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gbase + src_off[i] + h * HD * 2), (lds_void*)(lds16 + buf * BUF + dst_off[i]), 16, 0, 0);
+    };
+    issue(0, 0);
+    for (int i = tid; i < ROWS; i += F16_NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
+    bf16x8 qn[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + ((size_t)b * N + qc) * p.ld + 32 * ks + 8 * grp);
+    f32x4 mean[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) mean[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < p.H; ++h) {
+        const unsigned char* tK = lds16 + (h & 1) * BUF;
+        const unsigned char* tV = tK + ROWS * 128;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+        // head h's pieces (issued one head ago) and q fragment have landed; every wave is past head h - 1: its buffer is free again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (h + 1 < p.H) {
+            issue(h + 1, (h + 1) & 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8*>(p.qkv + ((size_t)b * N + qc) * p.ld + (h + 1) * HD + 32 * ks + 8 * grp);
+        }
+        if (!active) continue;
+        f32x4 s[NT16];
+        float mraw = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(tK + row_off(t * 16 + l15, ks * 4 + grp)), qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mraw = fmaxf(mraw, s[t][i]);
+        }
+        mraw = fmaxf(mraw, __shfl_xor(mraw, 16, 64));
+        mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+        const float m1 = mraw * c1;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            const int key0 = t * 16 + 4 * grp;
+            float keep[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (POLICY) {
+                const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
+                keep[0] = kp.x; keep[1] = kp.y; keep[2] = kp.z; keep[3] = kp.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool real = key0 + i < N;
+                float e = __builtin_amdgcn_exp2f(s[t][i] * c1 - m1);
+                if constexpr (POLICY) e *= (key0 + i == qself) ? 1.0f : keep[i];
+                else e = real ? e : 0.f;
+                sum += e;
+                s[t][i] = e + (real ? c : 0.f);                    // unnormalised probability (+ eps / N on the real keys)
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float zi = 1.0f / (sum + SOFTMAX_EPS);
+        if (grp == 0 && q < N) {
+            const size_t si = ((size_t)b * p.H + h) * N + q;
+            p.rowmax[si] = mraw * p.scale;
+            p.zinv[si] = zi;
+        }
+        if (p.headmean) {
+#pragma unroll
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mean[t][i] += s[t][i] * zi;
+        }
+        f32x4 o[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < (NT16 + 1) / 2; ++tp) {
+            constexpr int LAST = NT16 - 1;
+            const bool second = 2 * tp + 1 <= LAST;               // compile-time after unrolling
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            const f32x4 a = s[2 * tp], bq = second ? s[(2 * tp + 1 <= LAST) ? 2 * tp + 1 : LAST] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const u32x4 u = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(bq[0], bq[1]), pack_bf16x2(bq[2], bq[3])};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr16(tV, 32 * tp, 16 * db, lane, second), pf, o[db], 0, 0, 0);
+        }
+        if (q < N) {
+            bf16_t* orow = p.out + ((size_t)b * N + q) * p.D + h * HD;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                *reinterpret_cast<uint2*>(orow + 16 * db + 4 * grp) = make_uint2(pack_bf16x2(o[db][0] * zi, o[db][1] * zi), pack_bf16x2(o[db][2] * zi, o[db][3] * zi));
+        }
+    }
+    if (p.headmean && active && q < N) {
+        const float invH = 1.0f / (float)p.H;
+        float* row = p.headmean + ((size_t)b * N + q) * p.NP;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            const int key0 = t * 16 + 4 * grp;
+            if (key0 < p.NP) *reinterpret_cast<float4*>(row + key0) = make_float4(mean[t][0] * invH, mean[t][1] * invH, mean[t][2] * invH, mean[t][3] * invH);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- head mean
 // grid: x = 128-query block, y = KT*32-key block, z = batch.  Loops over heads, K tile restaged per head.
 template <int HD, int KT>
@@ -743,6 +910,38 @@ int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax,
         PPF_LAUNCH_CHECK();
         return 0;
     });
+}
+
+// The same forward pass with the head-mean map (NP = N rounded up to a multiple of 4, pad columns 0; NULL: no map) written by the SAME
+// launch (attn_fwd16_kernel): ppf_attn_fwd_hm_supported = 1 for head_dim 64 and N <= 208, else callers use ppf_attn_fwd + ppf_attn_headmean.
+int ppf_attn_fwd_hm_supported(int H, int N, int D) { return H > 0 && D % H == 0 && D / H == 64 && N > 0 && N <= 208 ? 1 : 0; }
+int ppf_attn_fwd_hm(const void* qkv, void* out, const float* policy, float* rowmax, float* zinv, float* headmean, int NP, int B, int H, int N,
+                    int D, int self_keep, int eps_n, hipStream_t stream) {
+    AttnParams p;
+    int rc = fill(p, qkv, B, H, N, D, policy, rowmax, zinv, self_keep, eps_n, "ppf_attn_fwd_hm");
+    if (rc) return rc;
+    PPF_CHECK_ARG(ppf_attn_fwd_hm_supported(H, N, D), PPF_ERR_SHAPE, "ppf_attn_fwd_hm: head_dim must be 64 and N <= 208 (H=%d N=%d D=%d)", H, N, D);
+    PPF_CHECK_ARG(headmean == nullptr || (NP >= N && NP % 4 == 0 && NP < N + 4), PPF_ERR_SHAPE, "ppf_attn_fwd_hm: NP=%d must be N rounded up to a multiple of 4", NP);
+    p.out = (bf16_t*)out; p.headmean = headmean; p.NP = NP;
+    const int nb = (N + 15) / 16;
+    const dim3 grid((nb + F16_WAVES - 1) / F16_WAVES, B);
+    constexpr int lds6 = Fwd16<64, 6>::LDS, lds13 = Fwd16<64, 13>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(attn_fwd16): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    if (N <= 96) {
+        if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, true>), grid, dim3(F16_NTHR), lds6, stream, p);
+        else hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false>), grid, dim3(F16_NTHR), lds6, stream, p);
+    } else {
+        if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, true>), grid, dim3(F16_NTHR), lds13, stream, p);
+        else hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false>), grid, dim3(F16_NTHR), lds13, stream, p);
+    }
+    PPF_LAUNCH_CHECK();
+    return 0;
 }
 
 // headmean[B][N][NP] = mean_h probabilities (NP = N rounded up to a multiple of 4; pad columns are written as 0).

@@ -229,13 +229,23 @@ def assemble_tokens_bwd(dx, dpos, dcls, B, Np, D, lead):
     return dtok
 
 
-def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True, eps_n=0):
-    """qkv bf16 [B*N, 3D] -> (out bf16 [B*N, D], rowmax, zinv [B,H,N])."""
+def attn_fwd_hm_ok(H, N, D):
+    """The one-launch forward + head-mean kernel (csrc/attention.hip attn_fwd16_kernel) covers this (heads, tokens, width)."""
+    return os.environ.get("PPF_ATTN_FWD16", "1") != "0" and bool(_lib.lib().ppf_attn_fwd_hm_supported(H, N, D))
+
+
+def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True, eps_n=0, headmean=None):
+    """qkv bf16 [B*N, 3D] -> (out bf16 [B*N, D], rowmax, zinv [B,H,N]).  headmean (fp32 [B, N, NP], only where attn_fwd_hm_ok): the
+    head-mean probability map of deit:104, written by the same launch."""
     _chk(qkv, torch.bfloat16)
     out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
     rowmax = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     zinv = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    _lib.call("ppf_attn_fwd", qkv, out, policy, rowmax, zinv, B, H, N, D, int(self_keep), int(eps_n))
+    if headmean is not None or (os.environ.get("PPF_ATTN_FWD16", "1") == "2" and attn_fwd_hm_ok(H, N, D)):
+        NP = (N + 3) // 4 * 4
+        _lib.call("ppf_attn_fwd_hm", qkv, out, policy, rowmax, zinv, headmean, NP, B, H, N, D, int(self_keep), int(eps_n))
+    else:
+        _lib.call("ppf_attn_fwd", qkv, out, policy, rowmax, zinv, B, H, N, D, int(self_keep), int(eps_n))
     return out, rowmax, zinv
 
 

@@ -48,6 +48,37 @@ def test_attn_fwd_and_headmean(B, H, N, D, use_policy):
         assert float(hm[:, :, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,N,D,use_policy", [(2, 6, 197, 384, False), (3, 3, 197, 192, True), (2, 2, 17, 128, True), (2, 6, 82, 384, True),
+                                                (1, 2, 208, 128, False), (2, 3, 96, 192, True), (2, 12, 197, 768, False)])
+@pytest.mark.parametrize("with_map", [True, False], ids=["with-map", "no-map"])
+def test_attn_fwd_one_launch_with_headmean(B, H, N, D, use_policy, with_map):
+    """attn_fwd16_kernel: forward pass, softmax statistics and the head-mean map from ONE launch, against the oracle and against the two
+    kernels it replaces (identical statistics contract for the backward kernel)."""
+    from protopformer_amd import ops
+    assert ops.attn_fwd_hm_ok(H, N, D)
+    qkv = _qkv(B, N, D, 3, 1.5)
+    pol = _policy(B, N, max(2, N // 3), 5) if use_policy else torch.ones(B, N)
+    ref_o, ref_p, _ = _oracle_attn(qkv, B, H, N, D, pol, True)
+    pol_d = pol.cuda() if use_policy else None
+    NP = (N + 3) // 4 * 4
+    hm = torch.full((B, N, NP), float("nan"), device="cuda") if with_map else None
+    if with_map:
+        out, rowmax, zinv = ops.attn_fwd(qkv.cuda(), B, H, N, D, policy=pol_d, headmean=hm)
+    else:
+        out = torch.empty((B * N, D), dtype=torch.bfloat16, device="cuda")
+        rowmax = torch.empty((B, H, N), device="cuda"); zinv = torch.empty_like(rowmax)
+        ops._lib.call("ppf_attn_fwd_hm", qkv.cuda(), out, pol_d, rowmax, zinv, None, NP, B, H, N, D, 1, 0)
+    assert_close(out.float(), ref_o, rtol=1e-2, atol=1e-2, what="attention out")
+    out2, rowmax2, zinv2 = torch.empty_like(out), torch.empty_like(rowmax), torch.empty_like(zinv)
+    ops._lib.call("ppf_attn_fwd", qkv.cuda(), out2, pol_d, rowmax2, zinv2, B, H, N, D, 1, 0)            # the 32-row two-pass kernel
+    assert_close(rowmax, rowmax2, rtol=1e-5, atol=1e-5, what="row max")
+    assert_close(zinv, zinv2, rtol=1e-4, atol=1e-7, what="1 / (sum + eps)")
+    if with_map:
+        assert_close(hm[:, :, :N], ref_p.mean(1), rtol=1e-3, atol=1e-6, what="head-mean probabilities")
+        if NP > N:
+            assert float(hm[:, :, N:].abs().max()) == 0.0
+
+
 def test_attn_masked_rows_known_answer():
     """Policy keeping only cls: every query's mass sits on {cls, itself}."""
     from protopformer_amd import ops

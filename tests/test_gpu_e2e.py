@@ -153,9 +153,11 @@ def test_real_shape_train_step_vs_oracle():
     rows = _grad_agreement(m, params)
     report("real_shape_tiny_peaky", logits=rel_err(logits, out["logits"]), ce=rel_err(ce, parts["ce"]), cov=rel_err(cov, parts["ppc_cov"]),
            mean=rel_err(mean, parts["ppc_mean"]), worst_cos=min(c for _, c in rows.values()), argmax_flips=n_flip, argmax_total=my_arg.numel())
-    # measured (attention sharpened 6x on purpose, far peakier than any trained model): logits 1.5e-3, CE 2.4e-4, PPC 1.7e-5
+    # measured (attention sharpened 6x on purpose, far peakier than any trained model): logits 1.5e-3 / 1.6e-3, CE 2.7e-4 / 2.5e-4, PPC cov
+    # 7e-6 / 2.4e-5, PPC mean 3e-5 / 8.7e-5 with the 32-row two-pass / the 16-row one-launch attention forward (bf16 probabilities summed
+    # in a different order); gates = 3 x the larger measurement
     assert rel_err(logits, out["logits"]) < 4.5e-3
-    assert rel_err(ce, parts["ce"]) < 8e-4 and rel_err(cov, parts["ppc_cov"]) < 6e-5 and rel_err(mean, parts["ppc_mean"]) < 6e-5
+    assert rel_err(ce, parts["ce"]) < 8e-4 and rel_err(cov, parts["ppc_cov"]) < 7.5e-5 and rel_err(mean, parts["ppc_mean"]) < 2.6e-4
     assert n_flip <= 0.06 * my_arg.numel(), (n_flip, my_arg.numel())           # the routing itself agrees on all but near-ties (measured 22 of 800)
     assert min(c for _, c in rows.values()) > COS_FLOOR, {k: v for k, v in rows.items() if v[1] <= COS_FLOOR}
 
