@@ -161,12 +161,12 @@ int ppf_th_softmax_bwd(const float* prob, float* da, void* ds16, const float* ww
  * th_dwl: no (B,H,N,N) fp32 tensor is materialised).  ppf_th_fused_supported: 1 when (heads, tokens, width) is covered (K and V images
  * of all heads must fit the 160 KiB LDS: head_dim in {32,48,64}, heads in {2,4}, N <= 224), else 0 -- callers then use the kernels above.
  * ppf_th_fwd: a16 = bf16 proj_w(softmax(proj_l(scale q k^T))) [B][H][N][NPK], hm = its head mean [B][N][NP], rowmax / zinv [B][H][N] =
- * softmax statistics of the mixed logits (saved for backward).
+ * softmax statistics of the mixed logits (saved for backward); out (optional) = the attention output A V, bf16 [B*N][D] (cait:128).
  * ppf_th_bwd: ds16 = bf16 dS [B][H][N][NPK] from dout = dO [B*N][D]; partial (>= ppf_th_bwd_partial_floats floats) receives one row of
  * parameter-gradient sums per workgroup; ppf_th_param_reduce adds their fixed-order (bit-reproducible) totals to dww, dbw, dbl, dwl. */
 int ppf_th_fused_supported(int H, int N, int D);
 int ppf_th_fwd(const void* qkv, const float* wl, const float* bl, const float* ww, const float* bw, void* a16, float* hm, float* rowmax,
-               float* zinv, int B, int H, int N, int D, int NP, int NPK, ppf_stream_t stream);
+               float* zinv, void* out, int B, int H, int N, int D, int NP, int NPK, ppf_stream_t stream);
 size_t ppf_th_bwd_partial_floats(int B, int H, int N);
 int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* bl, const float* ww, const float* rowmax, const float* zinv,
                void* ds16, float* partial, int B, int H, int N, int D, int NPK, ppf_stream_t stream);

@@ -50,7 +50,7 @@ SIGS = {
     "ppf_th_dwl": "ppp" "iiiii" "s",
     "ppf_th_softmax_mix": "ppppp" "iiiii" "s",
     "ppf_th_softmax_bwd": "pppppppp" "iiiii" "s",
-    "ppf_th_fwd": "ppppppppp" "iiiiii" "s",
+    "ppf_th_fwd": "pppppppppp" "iiiiii" "s",
     "ppf_th_bwd": "ppppppppp" "iiiii" "s",
     "ppf_th_param_reduce": "p" "iii" "pppp" "s",
     "ppf_class_attn_fwd": "pppppppp" "iiii" "s",

@@ -112,9 +112,13 @@ def _th_attention_fwd(blk, qkv, B, H, N, D, hm_slot):
     """Talking-heads attention (cait:115-130) from packed qkv; returns (out bf16 [B*N,D], P fp32, A bf16)."""
     hd = D // H
     if ops.th_fused_ok(H, N, D):
-        # one launch, nothing of size N x N in fp32: only the softmax statistics are kept for backward
-        a16, rowmax, zinv = ops.th_fwd(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot, B, H, N, D)
+        # one launch up to and including A.V, nothing of size N x N in fp32: only the softmax statistics (and the bf16 A the dV product reads)
+        # are kept for backward
+        a16, rowmax, zinv, ao = ops.th_fwd(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot, B, H, N, D,
+                                           with_out=os.environ.get("PPF_TH_PV", "1") != "0")
         sp = (rowmax, zinv)
+        if ao is not None:
+            return ao, sp, a16
     else:
         sp = ops.th_scores(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, B, H, N, D)
         a16 = ops.th_softmax_mix(sp, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot)      # sp now holds P

@@ -444,6 +444,7 @@ struct ThFusedParams {
     const bf16_t* dout;     // [B*N][D]            backward
     const float* wl; const float* bl; const float* ww; const float* bw;
     bf16_t* a16;            // fwd out [B][H][N][NPK]   A_g = sum_h Ww[g,h] P_h + bw[g]
+    bf16_t* out;            // fwd out [B*N][D]         O_g = A_g V_g (cait:128), or null: the caller multiplies
     float* hm;              // fwd out [B][N][NP]       mean over heads of A
     float* rowmax;          // [B][H][N]  fwd out / bwd in
     float* zinv;            // [B][H][N]
@@ -482,7 +483,21 @@ __device__ __forceinline__ bf16x8 th_frag_global(const bf16_t* src, size_t row, 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// grid (ceil(ceil(N / 16) / 7), B), 7 waves; LDS: K image of all heads
+// first operand of the A.V product, read transposed from the V image: output index d = dbase + (lane & 15), contraction slots
+// 8 (lane >> 4) + j <-> keys kb + 4 (lane >> 4) + j (j < 4) and kb + 16 + 4 (lane >> 4) + (j - 4): the register order of two adjacent
+// 16-key probability tiles.  Rows past N repeat the last valid one (their probabilities are zero).
+template <int HD>
+__device__ __forceinline__ bf16x8 th_frag_tr(const unsigned char* img, int N, int h, int kb, int dbase, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int s = lane & 15, grp = lane >> 4;
+    const int d = dbase + 4 * (s & 3);
+    const int r0 = min(kb + 4 * grp + (s >> 2), N - 1), r1 = min(kb + 16 + 4 * grp + (s >> 2), N - 1);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + ((size_t)(h * N + r0) * HD + d) * 2));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + ((size_t)(h * N + r1) * HD + d) * 2));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// grid (ceil(ceil(N / 16) / 7), B), 7 waves; LDS: K image of all heads (+ the V image when the A.V product runs here)
 template <int HD, int H>
 __global__ __launch_bounds__(TH_NTHR, 1) void th_fwd_kernel(const ThFusedParams p) {
     constexpr int KS = (HD + 31) / 32;
@@ -498,6 +513,8 @@ __global__ __launch_bounds__(TH_NTHR, 1) void th_fwd_kernel(const ThFusedParams 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[h][ks] = th_frag_global<HD>(base, (size_t)qc, 3 * p.D, h * HD, ks, lane, true);
     th_stage<HD, H>(tK, base + p.D, N, 3 * p.D, tid);
+    const unsigned char* tV = th_lds + (size_t)H * N * HD * 2;
+    if (p.out) th_stage<HD, H>(th_lds + (size_t)H * N * HD * 2, base + 2 * p.D, N, 3 * p.D, tid);
     float wl[H][H], ww[H][H], blv[H], bwv[H];
 #pragma unroll
     for (int g = 0; g < H; ++g) {
@@ -565,8 +582,16 @@ __global__ __launch_bounds__(TH_NTHR, 1) void th_fwd_kernel(const ThFusedParams 
             p.rowmax[si] = mm; p.zinv[si] = zi[g];
         }
     }
-    // pass 2: P_g = softmax(S'_g), A_g = sum_h Ww[g,h] P_h + bw[g]  ->  bf16 operand of A.V and the head mean (rollout input)
+    // pass 2: P_g = softmax(S'_g), A_g = sum_h Ww[g,h] P_h + bw[g]  ->  bf16 (saved: operand of the dV product), the head mean (rollout
+    // input) and, with p.out, O_g = A_g V_g right here: the two tiles of a trip are exactly one 32-key contraction step
+    constexpr int DB = HD / 16;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     const float ih = 1.0f / (float)H;
+    f32x4 o[H][DB];
+#pragma unroll
+    for (int g = 0; g < H; ++g)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[g][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int t2 = 0; t2 < NT2; ++t2) {
         f32x4 s[2][H];
@@ -579,6 +604,7 @@ __global__ __launch_bounds__(TH_NTHR, 1) void th_fwd_kernel(const ThFusedParams 
                 for (int ks = 0; ks < KS; ++ks)
                     s[u][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag<HD>(tK, N, h, t2 * 32 + u * 16, ks, lane), qf[h][ks], s[u][h], 0, 0, 0);
             }
+        uint32_t pk[H][4];                                  // bf16 pairs of A_g: [u = 0: keys 0-1, 2-3 | u = 1: keys 0-1, 2-3]
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int key0 = t2 * 32 + u * 16 + 4 * grp;
@@ -605,16 +631,34 @@ __global__ __launch_bounds__(TH_NTHR, 1) void th_fwd_kernel(const ThFusedParams 
                 }
                 mean[i] = mu * ih;
             }
+#pragma unroll
+            for (int g = 0; g < H; ++g) { pk[g][2 * u] = pack_bf16x2(av[g][0], av[g][1]); pk[g][2 * u + 1] = pack_bf16x2(av[g][2], av[g][3]); }
             if (q < N) {
                 if (key0 < p.NPK) {
 #pragma unroll
-                    for (int g = 0; g < H; ++g)
-                        *reinterpret_cast<uint2*>(p.a16 + (((size_t)b * H + g) * N + q) * p.NPK + key0) =
-                            make_uint2(pack_bf16x2(av[g][0], av[g][1]), pack_bf16x2(av[g][2], av[g][3]));
+                    for (int g = 0; g < H; ++g) *reinterpret_cast<uint2*>(p.a16 + (((size_t)b * H + g) * N + q) * p.NPK + key0) = make_uint2(pk[g][2 * u], pk[g][2 * u + 1]);
                 }
                 if (key0 < p.NP) *reinterpret_cast<float4*>(p.hm + ((size_t)b * N + q) * p.NP + key0) = make_float4(mean[0], mean[1], mean[2], mean[3]);
             }
         }
+        if (p.out) {                                        // uniform
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                const u32x4 uu = {pk[g][0], pk[g][1], pk[g][2], pk[g][3]};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, uu);
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+                    o[g][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th_frag_tr<HD>(tV, N, g, t2 * 32, db * 16, lane), pf, o[g][db], 0, 0, 0);
+            }
+        }
+    }
+    if (p.out && q < N) {
+        bf16_t* orow = p.out + ((size_t)b * N + q) * p.D;
+#pragma unroll
+        for (int g = 0; g < H; ++g)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                *reinterpret_cast<uint2*>(orow + g * HD + db * 16 + 4 * grp) = make_uint2(pack_bf16x2(o[g][db][0], o[g][db][1]), pack_bf16x2(o[g][db][2], o[g][db][3]));
     }
 }
 
@@ -877,7 +921,8 @@ int ppf_th_softmax_bwd(const float* prob, float* da, void* ds16, const float* ww
 
 // Fused talking-heads attention, forward part up to the mixed probabilities (cait:119-126): from packed qkv [B*N][3D] computes
 // A = proj_w(softmax(proj_l(scale q k^T))) as bf16 a16 [B][H][N][NPK] (zero padded; the operand of the A.V product), its head mean
-// hm [B][N][NP] (rollout input, cait:228) and the softmax statistics rowmax / zinv [B][H][N] the backward kernel recomputes P from.
+// hm [B][N][NP] (rollout input, cait:228), the softmax statistics rowmax / zinv [B][H][N] the backward kernel recomputes P from and, when
+// out != NULL, the attention output O = A V as bf16 [B*N][D] (cait:128) from the same launch.
 // Returns PPF_ERR_SHAPE for (head_dim, heads, N) combinations it does not cover (see ppf_th_fused_supported).
 int ppf_th_fused_supported(int H, int N, int D) {
     if (H <= 0 || D % H != 0) return 0;
@@ -887,14 +932,14 @@ int ppf_th_fused_supported(int H, int N, int D) {
     return (size_t)2 * H * N * hd * 2 + TH_WAVES * (2 * H * H + 2 * H) * sizeof(float) <= 160 * 1024 ? 1 : 0;
 }
 int ppf_th_fwd(const void* qkv, const float* wl, const float* bl, const float* ww, const float* bw, void* a16, float* hm, float* rowmax, float* zinv,
-               int B, int H, int N, int D, int NP, int NPK, hipStream_t stream) {
+               void* out, int B, int H, int N, int D, int NP, int NPK, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && ppf_th_fused_supported(H, N, D), PPF_ERR_SHAPE, "ppf_th_fwd: unsupported shape (B=%d H=%d N=%d D=%d)", B, H, N, D);
     PPF_CHECK_ARG(NP % 4 == 0 && NPK % 8 == 0 && NPK >= NP && NP >= N && NPK <= 256, PPF_ERR_SHAPE, "ppf_th_fwd: bad padding");
     ThFusedParams p = ThFusedParams(); p.qkv = (const bf16_t*)qkv; p.wl = wl; p.bl = bl; p.ww = ww; p.bw = bw; p.a16 = (bf16_t*)a16; p.hm = hm;
-    p.rowmax = rowmax; p.zinv = zinv; p.B = B; p.N = N; p.D = D; p.NP = NP; p.NPK = NPK; p.scale = 1.0f / sqrtf((float)(D / H));
+    p.rowmax = rowmax; p.zinv = zinv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.D = D; p.NP = NP; p.NPK = NPK; p.scale = 1.0f / sqrtf((float)(D / H));
     return dispatch_th(D / H, H, "ppf_th_fwd", [&](auto hd, auto hv) {
         constexpr int HD = decltype(hd)::value, HV = decltype(hv)::value;
-        const size_t lds = (size_t)HV * N * HD * 2;
+        const size_t lds = (size_t)(out ? 2 : 1) * HV * N * HD * 2;
         auto k = th_fwd_kernel<HD, HV>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }

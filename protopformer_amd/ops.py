@@ -527,15 +527,17 @@ def th_fused_ok(H, N, D):
     return os.environ.get("PPF_TH_FUSED", "1") != "0" and bool(_lib.lib().ppf_th_fused_supported(H, N, D))
 
 
-def th_fwd(qkv, wl, bl, ww, bw, hm_out, B, H, N, D):
-    """cait:119-126 in one launch: returns (a16 bf16 [B,H,N,NPK] = proj_w(softmax(proj_l(scale q k^T))), rowmax, zinv [B,H,N]);
-    hm_out [B,N,NP] receives the head mean of the mixed probabilities (rollout input)."""
+def th_fwd(qkv, wl, bl, ww, bw, hm_out, B, H, N, D, with_out=True):
+    """cait:119-128 in one launch: returns (a16 bf16 [B,H,N,NPK] = proj_w(softmax(proj_l(scale q k^T))), rowmax, zinv [B,H,N], out);
+    hm_out [B,N,NP] receives the head mean of the mixed probabilities (rollout input); out = a16 @ v as bf16 [B*N, D] (None when
+    with_out is False: the caller multiplies)."""
     NP, NPK = (N + 3) // 4 * 4, (N + 7) // 8 * 8
     a16 = torch.empty((B, H, N, NPK), dtype=torch.bfloat16, device=qkv.device)
     rowmax = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     zinv = torch.empty_like(rowmax)
-    _lib.call("ppf_th_fwd", qkv, wl, bl, ww, bw, a16, hm_out, rowmax, zinv, B, H, N, D, NP, NPK)
-    return a16, rowmax, zinv
+    out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device) if with_out else None
+    _lib.call("ppf_th_fwd", qkv, wl, bl, ww, bw, a16, hm_out, rowmax, zinv, out, B, H, N, D, NP, NPK)
+    return a16, rowmax, zinv, out
 
 
 def th_bwd(qkv, dout, wl, bl, ww, rowmax, zinv, B, H, N, D):

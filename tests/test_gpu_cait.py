@@ -30,15 +30,21 @@ def _th_forward(qkv16, wl, bl, ww, bw, B, H, N, D):
     return ao, prob, a16, hm
 
 
-FUSED = pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "materialised"])
+FUSED = pytest.mark.parametrize("fused", ["1", "pv0", "0"], ids=["fused", "fused-separate-AV", "materialised"])
+
+
+def _set_th_mode(monkeypatch, fused):
+    """fused: one launch incl. A.V; pv0: the fused kernel up to A, the A.V product as a batched GEMM; 0: the materialising kernels."""
+    monkeypatch.setenv("PPF_TH_FUSED", "0" if fused == "0" else "1")
+    monkeypatch.setenv("PPF_TH_PV", "0" if fused == "pv0" else "1")
 
 
 @FUSED
 def test_talking_heads_forward_golden(fused, monkeypatch):
     """TalkingHeadAttn.forward on the reference's weights/inputs (ops_real.npz), qkv/proj through the GEMM kernel."""
     from protopformer_amd import ops
-    monkeypatch.setenv("PPF_TH_FUSED", fused)
-    assert ops.th_fused_ok(4, 196, 192) == (fused == "1")
+    _set_th_mode(monkeypatch, fused)
+    assert ops.th_fused_ok(4, 196, 192) == (fused != "0")
     z = load_npz("ops_real.npz")
     c = gi.cait_inputs()
     B, H, N, D = c["B"], c["H"], c["N"], c["D"]
@@ -60,7 +66,7 @@ def test_talking_heads_forward_golden(fused, monkeypatch):
 @FUSED
 def test_talking_heads_backward_vs_oracle(fused, monkeypatch):
     from protopformer_amd import ops
-    monkeypatch.setenv("PPF_TH_FUSED", fused)
+    _set_th_mode(monkeypatch, fused)
     B, H, N, D = 2, 4, 196, 192
     hd = D // H
     g = torch.Generator().manual_seed(3)
