@@ -84,22 +84,30 @@ _CU_COUNT = {}
 
 
 def rowgemm_tile_rows(M, rows_per_sample, device=None, backward=False):
-    """Tile height for the full-row GEMMs: one sample per workgroup, or half a sample when whole samples would leave a third of the CUs
-    without a workgroup (batch 128 on 256 CUs: 128 tiles of 197 rows -> 255 tiles of 99).  Tiles need not end on sample boundaries: every
-    epilogue is row-wise and the DropPath scale is indexed by the global row (rows_per_group).
-    Backward keeps whole samples: there the CUs these one-per-CU workgroups leave free run the side stream's weight-gradient GEMMs
-    (measured, deit_tiny batch 128: half-sample tiles in backward -2 %, in forward +1..3 %; PPF_ROWGEMM_SPLIT=0 / 2 = never / both)."""
+    """Tile height for the full-row GEMMs: one sample per workgroup, or less when whole samples would leave a third of the CUs without a
+    workgroup (batch 128 on 256 CUs: 128 tiles of 197 rows).  Tiles need not end on sample boundaries: every epilogue is row-wise and the
+    DropPath scale is indexed by the global row (rows_per_group).
+    Forward: half a sample (255 tiles of 99 rows).  backward=True (callers whose side stream is busy with weight-gradient GEMMs while
+    these one-per-CU workgroups run): tiles for ~62 % of the CUs, the rest stays free for the side stream -- measured on deit_tiny batch
+    128, img/s: whole samples 24.3k, 144-176 rows 24.9-25.0k, half samples 23.6k.  PPF_ROWGEMM_SPLIT=0 / 2 = never / half samples
+    everywhere; PPF_ROWGEMM_BWD_ROWS=n: explicit backward height (measurement switches)."""
     mode = os.environ.get("PPF_ROWGEMM_SPLIT", "1")
-    if mode == "0" or (backward and mode != "2"):
+    if mode == "0":
         return rows_per_sample
+    if backward and os.environ.get("PPF_ROWGEMM_BWD_ROWS"):
+        return min(int(os.environ["PPF_ROWGEMM_BWD_ROWS"]), rows_per_sample)
     dev = torch.cuda.current_device() if device is None else device
     cus = _CU_COUNT.get(dev)
     if cus is None:
         cus = _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     tiles = (M + rows_per_sample - 1) // rows_per_sample
-    if 3 * tiles <= 2 * cus and rows_per_sample > 16:
-        return (rows_per_sample + 1) // 2
-    return rows_per_sample
+    if 3 * tiles > 2 * cus or rows_per_sample <= 16:
+        return rows_per_sample
+    half = (rows_per_sample + 1) // 2
+    if backward and mode != "2":
+        target = max(1, int(0.62 * cus))
+        return max(half, min(rows_per_sample, (M + target - 1) // target))
+    return half
 
 
 def rowgemm_bf16(a, b, rows_per_tile, bias=None):
