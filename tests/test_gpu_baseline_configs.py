@@ -126,8 +126,12 @@ def test_baseline_config_full_batch_properties(name):
     torch.cuda.empty_cache()
     m2, opt2, losses2 = _run_steps(c, 5, graph=False)
     # no float atomics on either path (CaiT's proj_l / proj_w gradients: per-workgroup partial rows + ordered sum since round 3): bit-identical repeat
-    assert losses2 == losses, (losses, losses2)
-    assert torch.equal(m2.flat_store().params, params_a)
+    from protopformer_amd import ops
+    if name.startswith("deit") or ops.th_fused_ok(4, 196, 192):
+        assert losses2 == losses, (losses, losses2)
+        assert torch.equal(m2.flat_store().params, params_a)
+    else:                                                         # PPF_TH_FUSED=0: the materialising talking-heads kernels sum proj_l / proj_w gradients with fp32 atomics
+        assert max(abs(a - b) / abs(a) for a, b in zip(losses, losses2)) < 1e-3, (losses, losses2)
     report(f"baseline_full_batch[{name}]", loss0=losses[0], loss4=losses[-1])
 
 
@@ -144,7 +148,11 @@ def test_baseline_config_graph_replay_equals_eager(name):
     out = json.loads(line[0][len("GRAPH_CHECK "):])
     eager, graphed = out["eager"], out["graphed"]
     assert out["steps"] == 4
-    assert graphed == eager, (eager, graphed)
+    from protopformer_amd import ops
+    if name.startswith("deit") or ops.th_fused_ok(4, 196, 192):
+        assert graphed == eager, (eager, graphed)
+    else:                                                         # PPF_TH_FUSED=0 (fp32 atomics in the fallback kernels)
+        assert max(abs(a - b) / abs(a) for a, b in zip(eager, graphed)) < 1e-3, (eager, graphed)
 
 
 def test_deit_small_bs256_compacted_equals_masked_blocks(monkeypatch):

@@ -351,8 +351,13 @@ def test_replayed_step_equals_eager_step(arch):
     assert rs.rec is not None and len(rs.rec.cmds) > 100
     # bit-identical for both backbones: every reduction of the step has a fixed order (CaiT's proj_l / proj_w gradients were fp32 atomics
     # until the fused talking-heads kernels of round 3 replaced them by per-workgroup partial rows + an ordered sum)
-    assert la == lb, (la, lb)
-    assert torch.equal(a.flat_store().params, b.flat_store().params) and torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.ema, opt_b.ema)
+    from protopformer_amd import ops
+    strict = arch == "deit" or ops.th_fused_ok(4, 196, 192)      # PPF_TH_FUSED=0: the fallback kernels' fp32 atomics are not reproducible
+    if strict:
+        assert la == lb, (la, lb)
+        assert torch.equal(a.flat_store().params, b.flat_store().params) and torch.equal(opt_a.exp_avg, opt_b.exp_avg) and torch.equal(opt_a.ema, opt_b.ema)
+    else:
+        assert max(abs(p_ - q_) / abs(p_) for p_, q_ in zip(la, lb)) < 5e-3, (la, lb)
     # a batch of another size (the short last batch of an epoch) runs eagerly on the same state and leaves the recorded list usable
     xs, ys = batches[0][0][:4].contiguous(), batches[0][1][:4].contiguous()
     l_a = float(train_one_step(a, crit, xs, ys, opt_a, epoch=20, max_norm=1.0)[0]); l_b = float(rs(xs, ys)[0])
@@ -360,5 +365,5 @@ def test_replayed_step_equals_eager_step(arch):
     l_a2 = float(train_one_step(a, crit, x, y, opt_a, epoch=20, max_norm=1.0)[0]); l_b2 = float(rs(x, y)[0])
     torch.cuda.synchronize()
     assert math.isfinite(l_b) and math.isfinite(l_b2) and opt_a.step_count == opt_b.step_count == 8
-    if arch == "cait":                            # DropPath off: the interleaved eager / replayed steps see the same (no) draws
+    if arch == "cait" and strict:                 # DropPath off: the interleaved eager / replayed steps see the same (no) draws
         assert l_a == l_b and l_a2 == l_b2 and torch.equal(a.flat_store().params, b.flat_store().params)
