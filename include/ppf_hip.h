@@ -171,6 +171,12 @@ size_t ppf_th_bwd_partial_floats(int B, int H, int N);
 int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* bl, const float* ww, const float* rowmax, const float* zinv,
                void* ds16, float* partial, int B, int H, int N, int D, int NPK, ppf_stream_t stream);
 int ppf_th_param_reduce(const float* partial, int B, int H, int N, float* dww, float* dbw, float* dbl, float* dwl, ppf_stream_t stream);
+/* the three per-head products behind ppf_th_bwd in one launch: dqkv [B*N][3D] bf16 <- dQ_h = scale dS_h K_h | dK_h = scale dS_h^T Q_h |
+ * dV_h = A_h^T dO_h from ds16 / a16 [B][H][N][NPK], packed qkv and dout [B*N][D] (ppf_th_grads_supported: N <= 208, head_dim 32/48/64;
+ * otherwise three ppf_gemm_bf16_batched calls) */
+int ppf_th_grads_supported(int H, int N, int D);
+int ppf_th_grads(const void* qkv, const void* dout, const void* ds16, const void* a16, void* dqkv, int B, int H, int N, int D, int NPK,
+                 ppf_stream_t stream);
 /* class attention: q [B][D] (cls rows, unscaled), k/v [B*N1][D] bf16; policy softmax WITHOUT the identity term (cait:58-59) */
 int ppf_class_attn_fwd(const void* q, const void* k, const void* v, const float* policy, float* attn, float* zinv, float* rowmean,
                        void* out, int B, int H, int N1, int D, ppf_stream_t stream);

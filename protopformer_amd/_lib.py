@@ -53,6 +53,7 @@ SIGS = {
     "ppf_th_fwd": "pppppppppp" "iiiiii" "s",
     "ppf_th_bwd": "ppppppppp" "iiiii" "s",
     "ppf_th_param_reduce": "p" "iii" "pppp" "s",
+    "ppf_th_grads": "ppppp" "iiiii" "s",
     "ppf_class_attn_fwd": "pppppppp" "iiii" "s",
     "ppf_class_attn_bwd": "ppppppppp" "iiii" "s",
     "ppf_merge3_cast": "pppp" "iii" "s",
@@ -118,6 +119,8 @@ def lib():
         _lib.ppf_attn_fwd_hm_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_th_fused_supported.restype = ctypes.c_int
         _lib.ppf_th_fused_supported.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_th_grads_supported.restype = ctypes.c_int
+        _lib.ppf_th_grads_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_th_bwd_partial_floats.restype = ctypes.c_size_t
         _lib.ppf_th_bwd_partial_floats.argtypes = [ctypes.c_int] * 3
         _lib.ppf_stream_mark.restype = ctypes.c_int64

@@ -239,10 +239,12 @@ def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
     dev = qkv.device
     scale = hd ** -0.5
     dqkv = torch.empty_like(qkv)
-    # dV_h[key][d] = sum_q A_h[q][key] dO_h[q][d]
-    ops.gemm_batched(a16, dao, ops._Off(dqkv, 2 * D), N, hd, N, NPK, D, 3 * D, True, True, False, 1.0, B, H,
-                     (H * N * NPK, N * NPK), (N * D, hd), (N * 3 * D, hd), kpad=1)
     gv = store.grad_view
+    one_launch = isinstance(prob, tuple) and ops.th_grads_ok(H, N, D)      # dQ, dK, dV by ops.th_grads behind th_bwd
+    if not one_launch:
+        # dV_h[key][d] = sum_q A_h[q][key] dO_h[q][d]
+        ops.gemm_batched(a16, dao, ops._Off(dqkv, 2 * D), N, hd, N, NPK, D, 3 * D, True, True, False, 1.0, B, H,
+                         (H * N * NPK, N * NPK), (N * D, hd), (N * 3 * D, hd), kpad=1)
     if isinstance(prob, tuple):
         # fused: dA, the two head mixes and the softmax backward in registers; the parameter-gradient sums leave the main stream
         rowmax, zinv = prob
@@ -258,6 +260,8 @@ def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
         ds16 = ops.th_softmax_bwd(prob, da, blk.attn.proj_w.weight, blk.attn.proj_l.weight, gv(blk.attn.proj_w.weight), gv(blk.attn.proj_w.bias),
                                   gv(blk.attn.proj_l.bias))
         ops.th_dwl(qkv, da, gv(blk.attn.proj_l.weight), B, H, N, D)                # da now holds dS'
+    if one_launch:
+        return ops.th_grads(qkv, dao, ds16, a16, dqkv, B, H, N, D)
     # dQ_h = scale * dS_h K_h ;  dK_h = scale * dS_h^T Q_h
     ops.gemm_batched(ds16, ops._Off(qkv, D), dqkv, N, hd, N, NPK, 3 * D, 3 * D, False, True, False, scale, B, H,
                      (H * N * NPK, N * NPK), (N * 3 * D, hd), (N * 3 * D, hd), kpad=1)

@@ -832,6 +832,135 @@ __global__ __launch_bounds__(TH_NTHR, 1) void th_bwd_kernel(const ThFusedParams 
     }
 }
 
+// The three per-head products behind th_bwd in ONE launch (they were three batched 128x128-tile GEMMs with 48 of 128 columns used):
+//   dQ_h = scale dS_h K_h,   dK_h = scale dS_h^T Q_h,   dV_h = A_h^T dO_h        (written into the packed dqkv rows)
+// One 4-wave workgroup per (sample, head).  K, Q and dO of the head sit in LDS as [token][head_dim] images (zero rows past N); dS and A
+// stream through a double buffer of 32-query tiles by LDS-DMA (a tile of the [B][H][N][NPK] tensors is one contiguous block).  All
+// operands that are contracted over their ROWS (K for dQ; Q, dO, dS, A for dK / dV) are read with ds_read_b64_tr_b16, every product is
+// v_mfma_f32_16x16x32_bf16 with swapped operands (output index d in the rows): dK / dV accumulate in registers over the query tiles
+// (wave w owns the key blocks w, w + 4, ...), dQ of a tile is complete after one pass over the keys.
+template <int HD>
+__global__ __launch_bounds__(256, 1) void th_grads_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ ds16,
+                                                          const bf16_t* __restrict__ a16, bf16_t* __restrict__ dqkv, int B, int H, int N, int D, int NPK,
+                                                          float scale) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    constexpr int DB = HD / 16, IMG_ROWS = 224, IMG = IMG_ROWS * HD * 2, QT = 32, MAXKB = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl[];
+    unsigned char* iK = gl;
+    unsigned char* iQ = gl + IMG;
+    unsigned char* iO = gl + 2 * IMG;
+    unsigned char* tiles = gl + 3 * IMG;                       // [2 buffers][dS tile | A tile], QT rows x NPK bf16 each
+    const int tile_bytes = QT * NPK * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l15 = lane & 15, s4 = l15 >> 2, c4 = 4 * (l15 & 3);
+    const int h = blockIdx.x, b = blockIdx.y, ld = 3 * D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
+    const unsigned char* gds = reinterpret_cast<const unsigned char*>(ds16 + ((size_t)b * H + h) * N * NPK);
+    const unsigned char* ga = reinterpret_cast<const unsigned char*>(a16 + ((size_t)b * H + h) * N * NPK);
+    const int nqt = (N + QT - 1) / QT, nkb = (N + 15) / 16, nks = (N + 31) / 32;
+    // a tile = QT rows of NPK bf16, contiguous in global memory; rows past N repeat the last one (they meet zero rows of Q / dO)
+    auto issue = [&](int qt, int buf) {
+        const int chunks = tile_bytes / 16;                    // 16-byte pieces of one tile
+        for (int c0 = wave * 64; c0 < chunks; c0 += 256) {
+            const int c = c0 + lane;
+            if (c0 + 64 <= chunks || c < chunks) {
+                const int cc = min(c, chunks - 1);
+                const int row = (cc * 16) / (NPK * 2), colb = cc * 16 - row * NPK * 2;
+                const size_t src = (size_t)min(qt * QT + row, N - 1) * NPK * 2 + colb;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gds + src), (lds_void*)(tiles + buf * 2 * tile_bytes + c0 * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(ga + src), (lds_void*)(tiles + buf * 2 * tile_bytes + tile_bytes + c0 * 16), 16, 0, 0);
+            }
+        }
+    };
+    issue(0, 0);
+    {   // K, Q, dO images: [IMG_ROWS][HD], zero rows past N
+        constexpr int CH = HD / 8;
+        for (int i = tid; i < IMG_ROWS * CH; i += 256) {
+            const int r = i / CH, c = i - r * CH;
+            uint4 k = make_uint4(0, 0, 0, 0), q = k, o = k;
+            if (r < N) {
+                k = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
+                q = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + c * 8);
+                o = *reinterpret_cast<const uint4*>(dob + (size_t)r * D + c * 8);
+            }
+            *reinterpret_cast<uint4*>(iK + (size_t)i * 16) = k;
+            *reinterpret_cast<uint4*>(iQ + (size_t)i * 16) = q;
+            *reinterpret_cast<uint4*>(iO + (size_t)i * 16) = o;
+        }
+    }
+    // transposed fragment: 8 contraction slots = rows r0 + 4 grp + j (j < 4) and r0 + 16 + 4 grp + (j - 4), output index col0 + (lane & 15)
+    auto tr = [&](const unsigned char* img, int pitch, int r0, int col0) -> bf16x8 {
+        const unsigned char* a0 = img + (size_t)(r0 + 4 * grp + s4) * pitch + (col0 + c4) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 16 * pitch));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    f32x4 dk[MAXKB][DB], dv[MAXKB][DB];
+#pragma unroll
+    for (int i = 0; i < MAXKB; ++i)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { dk[i][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int qt = 0; qt < nqt; ++qt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // tile qt (and, first trip, the images) visible; every wave is past tile qt - 1
+        if (qt + 1 < nqt) issue(qt + 1, (qt + 1) & 1);
+        const unsigned char* tS = tiles + (qt & 1) * 2 * tile_bytes;
+        const unsigned char* tA = tS + tile_bytes;
+        // ---- dK, dV: contraction over the 32 queries of this tile
+        bf16x8 qT[DB], oT[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { qT[db] = tr(iQ, HD * 2, qt * QT, 16 * db); oT[db] = tr(iO, HD * 2, qt * QT, 16 * db); }
+#pragma unroll
+        for (int i = 0; i < MAXKB; ++i) {
+            const int kb = wave + 4 * i;
+            if (kb < nkb) {                                    // wave-uniform
+                const bf16x8 sT = tr(tS, NPK * 2, 0, 16 * kb), aT = tr(tA, NPK * 2, 0, 16 * kb);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    dk[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[db], sT, dk[i][db], 0, 0, 0);
+                    dv[i][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT[db], aT, dv[i][db], 0, 0, 0);
+                }
+            }
+        }
+        // ---- dQ of this tile: 2 query blocks x DB d-blocks output tiles, dealt to the waves; contraction over all keys
+        for (int ti = wave; ti < 2 * DB; ti += 4) {
+            const int qb = ti / DB, db = ti - qb * DB;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* srow = tS + (size_t)(16 * qb + l15) * NPK * 2;
+            for (int ks = 0; ks < nks; ++ks) {
+                const bf16x8 kT = tr(iK, HD * 2, 32 * ks, 16 * db);
+                // second operand: this lane's query row, keys 32 ks + 4 grp + j and 32 ks + 16 + 4 grp + j (the slot order of tr)
+                const int k0 = 32 * ks + 4 * grp;
+                uint2 lo = make_uint2(0, 0), hi = lo;
+                if (k0 < NPK) lo = *reinterpret_cast<const uint2*>(srow + k0 * 2);
+                if (k0 + 16 < NPK) hi = *reinterpret_cast<const uint2*>(srow + (k0 + 16) * 2);
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                const u32x4 u = {lo.x, lo.y, hi.x, hi.y};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, __builtin_bit_cast(bf16x8, u), acc, 0, 0, 0);
+            }
+            const int q = qt * QT + 16 * qb + l15;
+            if (q < N)
+                *reinterpret_cast<uint2*>(dqkv + ((size_t)b * N + q) * ld + h * HD + 16 * db + 4 * grp) =
+                    make_uint2(pack_bf16x2(acc[0] * scale, acc[1] * scale), pack_bf16x2(acc[2] * scale, acc[3] * scale));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXKB; ++i) {
+        const int key = 16 * (wave + 4 * i) + l15;
+        if (wave + 4 * i < nkb && key < N) {
+            bf16_t* row = dqkv + ((size_t)b * N + key) * ld + h * HD + 4 * grp;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                *reinterpret_cast<uint2*>(row + D + 16 * db) = make_uint2(pack_bf16x2(dk[i][db][0] * scale, dk[i][db][1] * scale), pack_bf16x2(dk[i][db][2] * scale, dk[i][db][3] * scale));
+                *reinterpret_cast<uint2*>(row + 2 * D + 16 * db) = make_uint2(pack_bf16x2(dv[i][db][0], dv[i][db][1]), pack_bf16x2(dv[i][db][2], dv[i][db][3]));
+            }
+        }
+    }
+}
+
 // out_j += sum over the workgroups' partial rows, fixed order (bit-reproducible): one workgroup per parameter-gradient element
 __global__ __launch_bounds__(256) void th_param_reduce_kernel(const float* __restrict__ partial, int nparts, int PW, int H, float* dww, float* dbw,
                                                               float* dbl, float* dwl) {
@@ -970,6 +1099,35 @@ int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* 
         return 0;
     });
 }
+// dqkv [B*N][3D] (bf16, every column written) from ds16 / a16 [B][H][N][NPK] (th_bwd's dS, th_fwd's A), packed qkv and dout = dO [B*N][D]:
+// dQ_h = scale dS_h K_h, dK_h = scale dS_h^T Q_h, dV_h = A_h^T dO_h -- the three products behind ppf_th_bwd in one launch.
+// Needs N <= 208 (16 key blocks on 4 waves), head_dim in {32, 48, 64} and the images + tile buffers in 160 KiB (ppf_th_grads_supported).
+int ppf_th_grads_supported(int H, int N, int D) {
+    if (H <= 0 || D % H != 0) return 0;
+    const int hd = D / H, NPK = (N + 7) / 8 * 8;
+    if (!(hd == 32 || hd == 48 || hd == 64) || N <= 0 || N > 208) return 0;
+    return (size_t)3 * 224 * hd * 2 + (size_t)4 * 32 * NPK * 2 + 64 <= 160 * 1024 ? 1 : 0;
+}
+int ppf_th_grads(const void* qkv, const void* dout, const void* ds16, const void* a16, void* dqkv, int B, int H, int N, int D, int NPK, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && ppf_th_grads_supported(H, N, D) && NPK == (N + 7) / 8 * 8, PPF_ERR_SHAPE, "ppf_th_grads: unsupported shape (B=%d H=%d N=%d D=%d NPK=%d)", B, H, N, D, NPK);
+    PPF_CHECK_ARG(qkv && dout && ds16 && a16 && dqkv, PPF_ERR_ARG, "ppf_th_grads: null pointer");
+    const int hd = D / H;
+    const size_t lds = (size_t)3 * 224 * hd * 2 + (size_t)4 * 32 * NPK * 2 + 64;      // + slack: the last transposed read of a tile overhangs its row by 16 bytes
+    const float scale = 1.0f / sqrtf((float)hd);
+#define PPF_TH_GRADS(HDV)                                                                                                                     \
+    {                                                                                                                                         \
+        auto k = th_grads_kernel<HDV>;                                                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(th_grads): %s", hipGetErrorString(e)); return (int)e; }                     \
+        hipLaunchKernelGGL(k, dim3(H, B), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)ds16,               \
+                           (const bf16_t*)a16, (bf16_t*)dqkv, B, H, N, D, NPK, scale);                                                        \
+    }
+    if (hd == 48) PPF_TH_GRADS(48) else if (hd == 64) PPF_TH_GRADS(64) else PPF_TH_GRADS(32)
+#undef PPF_TH_GRADS
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
 int ppf_th_param_reduce(const float* partial, int B, int H, int N, float* dww, float* dbw, float* dbl, float* dwl, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && (H == 2 || H == 4) && N > 0, PPF_ERR_SHAPE, "ppf_th_param_reduce: bad shape");
     const int PW = 2 * H * H + 2 * H;

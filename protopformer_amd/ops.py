@@ -558,6 +558,16 @@ def th_bwd(qkv, dout, wl, bl, ww, rowmax, zinv, B, H, N, D):
     return ds16, partial
 
 
+def th_grads_ok(H, N, D):
+    return os.environ.get("PPF_TH_GRADS", "1") != "0" and bool(_lib.lib().ppf_th_grads_supported(H, N, D))
+
+
+def th_grads(qkv, dout, ds16, a16, dqkv, B, H, N, D):
+    """dqkv bf16 [B*N, 3D] <- dQ | dK | dV of the talking-heads attention from dS (th_bwd), A (th_fwd), q / k (packed qkv) and dO: one launch."""
+    _lib.call("ppf_th_grads", qkv, dout, ds16, a16, dqkv, B, H, N, D, a16.shape[-1])
+    return dqkv
+
+
 def th_param_reduce(partial, B, H, N, dww, dbw, dbl, dwl):
     _lib.call("ppf_th_param_reduce", partial, B, H, N, dww, dbw, dbl, dwl)
 
