@@ -834,19 +834,20 @@ __global__ __launch_bounds__(TH_NTHR, 1) void th_bwd_kernel(const ThFusedParams 
 
 // The three per-head products behind th_bwd in ONE launch (they were three batched 128x128-tile GEMMs with 48 of 128 columns used):
 //   dQ_h = scale dS_h K_h,   dK_h = scale dS_h^T Q_h,   dV_h = A_h^T dO_h        (written into the packed dqkv rows)
-// One 4-wave workgroup per (sample, head).  K, Q and dO of the head sit in LDS as [token][head_dim] images (zero rows past N); dS and A
+// One 8-wave workgroup per (sample, head).  K, Q and dO of the head sit in LDS as [token][head_dim] images (zero rows past N); dS and A
 // stream through a double buffer of 32-query tiles by LDS-DMA (a tile of the [B][H][N][NPK] tensors is one contiguous block).  All
 // operands that are contracted over their ROWS (K for dQ; Q, dO, dS, A for dK / dV) are read with ds_read_b64_tr_b16, every product is
 // v_mfma_f32_16x16x32_bf16 with swapped operands (output index d in the rows): dK / dV accumulate in registers over the query tiles
-// (wave w owns the key blocks w, w + 4, ...), dQ of a tile is complete after one pass over the keys.
+// (wave w owns the key blocks w and w + 8), dQ of a tile is complete after one pass over the keys.
+constexpr int TG_WAVES = 8, TG_NTHR = TG_WAVES * 64;
 template <int HD>
-__global__ __launch_bounds__(256, 1) void th_grads_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ ds16,
-                                                          const bf16_t* __restrict__ a16, bf16_t* __restrict__ dqkv, int B, int H, int N, int D, int NPK,
-                                                          float scale) {
+__global__ __launch_bounds__(TG_NTHR, 1) void th_grads_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ ds16,
+                                                              const bf16_t* __restrict__ a16, bf16_t* __restrict__ dqkv, int B, int H, int N, int D, int NPK,
+                                                              float scale) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
-    constexpr int DB = HD / 16, IMG_ROWS = 224, IMG = IMG_ROWS * HD * 2, QT = 32, MAXKB = 4;
+    constexpr int DB = HD / 16, IMG_ROWS = 224, IMG = IMG_ROWS * HD * 2, QT = 32, MAXKB = 2, CH = HD / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char gl[];
     unsigned char* iK = gl;
     unsigned char* iQ = gl + IMG;
@@ -855,40 +856,41 @@ __global__ __launch_bounds__(256, 1) void th_grads_kernel(const bf16_t* __restri
     const int tile_bytes = QT * NPK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l15 = lane & 15, s4 = l15 >> 2, c4 = 4 * (l15 & 3);
     const int h = blockIdx.x, b = blockIdx.y, ld = 3 * D;
-    const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
-    const bf16_t* dob = dout + (size_t)b * N * D + h * HD;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(qkv + (size_t)b * N * ld + h * HD);
+    const unsigned char* dob = reinterpret_cast<const unsigned char*>(dout + (size_t)b * N * D + h * HD);
     const unsigned char* gds = reinterpret_cast<const unsigned char*>(ds16 + ((size_t)b * H + h) * N * NPK);
     const unsigned char* ga = reinterpret_cast<const unsigned char*>(a16 + ((size_t)b * H + h) * N * NPK);
     const int nqt = (N + QT - 1) / QT, nkb = (N + 15) / 16, nks = (N + 31) / 32;
-    // a tile = QT rows of NPK bf16, contiguous in global memory; rows past N repeat the last one (they meet zero rows of Q / dO)
+    // everything enters LDS by LDS-DMA (lane-linear destination, per-lane source).  A tile = QT rows of NPK bf16, contiguous in global
+    // memory; rows past N repeat the last one (they meet zero rows of Q / dO).
     auto issue = [&](int qt, int buf) {
         const int chunks = tile_bytes / 16;                    // 16-byte pieces of one tile
-        for (int c0 = wave * 64; c0 < chunks; c0 += 256) {
+        for (int c0 = wave * 64; c0 < chunks; c0 += TG_NTHR) {
             const int c = c0 + lane;
-            if (c0 + 64 <= chunks || c < chunks) {
-                const int cc = min(c, chunks - 1);
-                const int row = (cc * 16) / (NPK * 2), colb = cc * 16 - row * NPK * 2;
+            if (c < chunks) {
+                const int row = (c * 16) / (NPK * 2), colb = c * 16 - row * NPK * 2;
                 const size_t src = (size_t)min(qt * QT + row, N - 1) * NPK * 2 + colb;
                 __builtin_amdgcn_global_load_lds((gbl_void*)(gds + src), (lds_void*)(tiles + buf * 2 * tile_bytes + c0 * 16), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gbl_void*)(ga + src), (lds_void*)(tiles + buf * 2 * tile_bytes + tile_bytes + c0 * 16), 16, 0, 0);
             }
         }
     };
-    issue(0, 0);
-    {   // K, Q, dO images: [IMG_ROWS][HD], zero rows past N
-        constexpr int CH = HD / 8;
-        for (int i = tid; i < IMG_ROWS * CH; i += 256) {
-            const int r = i / CH, c = i - r * CH;
-            uint4 k = make_uint4(0, 0, 0, 0), q = k, o = k;
-            if (r < N) {
-                k = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
-                q = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + c * 8);
-                o = *reinterpret_cast<const uint4*>(dob + (size_t)r * D + c * 8);
-            }
-            *reinterpret_cast<uint4*>(iK + (size_t)i * 16) = k;
-            *reinterpret_cast<uint4*>(iQ + (size_t)i * 16) = q;
-            *reinterpret_cast<uint4*>(iO + (size_t)i * 16) = o;
+    // K, Q, dO images [IMG_ROWS][HD]: rows < N by DMA, rows past N zero-filled
+    for (int c0 = wave * 64; c0 < N * CH; c0 += TG_NTHR) {
+        const int c = c0 + lane;
+        if (c < N * CH) {
+            const int r = c / CH, cc = c - r * CH;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + ((size_t)r * ld + D) * 2 + cc * 16), (lds_void*)(iK + c0 * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + (size_t)r * ld * 2 + cc * 16), (lds_void*)(iQ + c0 * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(dob + (size_t)r * D * 2 + cc * 16), (lds_void*)(iO + c0 * 16), 16, 0, 0);
         }
+    }
+    issue(0, 0);
+    for (int i = N * CH + tid; i < IMG_ROWS * CH; i += TG_NTHR) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(iK + (size_t)i * 16) = z;
+        *reinterpret_cast<uint4*>(iQ + (size_t)i * 16) = z;
+        *reinterpret_cast<uint4*>(iO + (size_t)i * 16) = z;
     }
     // transposed fragment: 8 contraction slots = rows r0 + 4 grp + j (j < 4) and r0 + 16 + 4 grp + (j - 4), output index col0 + (lane & 15)
     auto tr = [&](const unsigned char* img, int pitch, int r0, int col0) -> bf16x8 {
@@ -909,13 +911,13 @@ __global__ __launch_bounds__(256, 1) void th_grads_kernel(const bf16_t* __restri
         if (qt + 1 < nqt) issue(qt + 1, (qt + 1) & 1);
         const unsigned char* tS = tiles + (qt & 1) * 2 * tile_bytes;
         const unsigned char* tA = tS + tile_bytes;
-        // ---- dK, dV: contraction over the 32 queries of this tile
+        // ---- dK, dV: contraction over the 32 queries of this tile; wave w owns the key blocks w and w + 8
         bf16x8 qT[DB], oT[DB];
 #pragma unroll
         for (int db = 0; db < DB; ++db) { qT[db] = tr(iQ, HD * 2, qt * QT, 16 * db); oT[db] = tr(iO, HD * 2, qt * QT, 16 * db); }
 #pragma unroll
         for (int i = 0; i < MAXKB; ++i) {
-            const int kb = wave + 4 * i;
+            const int kb = wave + TG_WAVES * i;
             if (kb < nkb) {                                    // wave-uniform
                 const bf16x8 sT = tr(tS, NPK * 2, 0, 16 * kb), aT = tr(tA, NPK * 2, 0, 16 * kb);
 #pragma unroll
@@ -925,8 +927,9 @@ __global__ __launch_bounds__(256, 1) void th_grads_kernel(const bf16_t* __restri
                 }
             }
         }
-        // ---- dQ of this tile: 2 query blocks x DB d-blocks output tiles, dealt to the waves; contraction over all keys
-        for (int ti = wave; ti < 2 * DB; ti += 4) {
+        // ---- dQ of this tile: 2 query blocks x DB d-blocks output tiles, dealt to the waves from the top (waves 7, 6, ... : the waves with
+        // one key block above take them first); contraction over all keys
+        for (int ti = TG_WAVES - 1 - wave; ti < 2 * DB; ti += TG_WAVES) {
             const int qb = ti / DB, db = ti - qb * DB;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             const unsigned char* srow = tS + (size_t)(16 * qb + l15) * NPK * 2;
@@ -949,8 +952,8 @@ __global__ __launch_bounds__(256, 1) void th_grads_kernel(const bf16_t* __restri
     }
 #pragma unroll
     for (int i = 0; i < MAXKB; ++i) {
-        const int key = 16 * (wave + 4 * i) + l15;
-        if (wave + 4 * i < nkb && key < N) {
+        const int key = 16 * (wave + TG_WAVES * i) + l15;
+        if (wave + TG_WAVES * i < nkb && key < N) {
             bf16_t* row = dqkv + ((size_t)b * N + key) * ld + h * HD + 4 * grp;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -1101,7 +1104,7 @@ int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* 
 }
 // dqkv [B*N][3D] (bf16, every column written) from ds16 / a16 [B][H][N][NPK] (th_bwd's dS, th_fwd's A), packed qkv and dout = dO [B*N][D]:
 // dQ_h = scale dS_h K_h, dK_h = scale dS_h^T Q_h, dV_h = A_h^T dO_h -- the three products behind ppf_th_bwd in one launch.
-// Needs N <= 208 (16 key blocks on 4 waves), head_dim in {32, 48, 64} and the images + tile buffers in 160 KiB (ppf_th_grads_supported).
+// Needs N <= 208 (13 key blocks on 8 waves x 2), head_dim in {32, 48, 64} and the images + tile buffers in 160 KiB (ppf_th_grads_supported).
 int ppf_th_grads_supported(int H, int N, int D) {
     if (H <= 0 || D % H != 0) return 0;
     const int hd = D / H, NPK = (N + 7) / 8 * 8;
@@ -1119,7 +1122,7 @@ int ppf_th_grads(const void* qkv, const void* dout, const void* ds16, const void
         auto k = th_grads_kernel<HDV>;                                                                                                        \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(th_grads): %s", hipGetErrorString(e)); return (int)e; }                     \
-        hipLaunchKernelGGL(k, dim3(H, B), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)ds16,               \
+        hipLaunchKernelGGL(k, dim3(H, B), dim3(TG_NTHR), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)ds16,               \
                            (const bf16_t*)a16, (bf16_t*)dqkv, B, H, N, D, NPK, scale);                                                        \
     }
     if (hd == 48) PPF_TH_GRADS(48) else if (hd == 64) PPF_TH_GRADS(64) else PPF_TH_GRADS(32)
