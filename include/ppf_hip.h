@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 5
+#define PPF_ABI_VERSION 6
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -264,6 +264,12 @@ int ppf_adamw_step(float* p, const float* g, float* m, float* v, float* ema, voi
 int ppf_adamw_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
                        const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
                        ppf_stream_t stream);
+/* ppf_adamw_step_dev with the reference's per-step non-finite-loss check (tools/engine_proto.py:66-70: print + sys.exit(1) in front of
+ * optimizer.step()) evaluated on the device: `loss` = the step's loss scalar (device); if it is NaN / inf nothing is updated and
+ * *nonfinite_flag = 1 (read by the host at its logging cadence: engine.train_one_epoch).  loss == NULL && flag == NULL: no check. */
+int ppf_adamw_step_guarded(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
+                           const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
+                           const float* loss, int* nonfinite_flag, ppf_stream_t stream);
 /* hyper[0..n) <- host_vals[0..n) (n <= 20), passed by value at enqueue time (safe when the host runs ahead of the device) */
 int ppf_hyper_set(float* hyper, const float* host_vals, int n, ppf_stream_t stream);
 /* clip_grad_norm_ (timm dispatch_clip_grad 'norm' via NativeScaler, engine_proto.py:74-76, main.py --clip-grad): hyper[19] =

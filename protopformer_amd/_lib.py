@@ -65,6 +65,7 @@ SIGS = {
     "ppf_th_attn_fwd_f32": "ppppp" "pp" "i" "iiii" "s",
     "ppf_class_attn_fwd_f32": "pppppp" "iiii" "s",
     "ppf_adamw_step_dev": "pppppp" "li" "pp" "ffff" "s",
+    "ppf_adamw_step_guarded": "pppppp" "li" "pp" "ffff" "pp" "s",
     "ppf_hyper_set": "ppi" "s",
     "ppf_clip_grad_scale": "pl" "ff" "ppp" "s",
     "ppf_droppath_scales": "pp" "ii" "Lp" "s",
@@ -79,7 +80,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 5               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 6               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
@@ -200,6 +201,7 @@ class Recorder:
 
     def __init__(self):
         self.cmds, self.keep, self.tickets, self.nslots, self.suspended = [], [], {}, 0, 0
+        self.main_stream = stream_ptr() if torch.cuda.is_available() else None      # torch's current stream while the step was recorded
 
     def add_call(self, name, fn, a, args):
         if name == "ppf_stream_wait_mark":
@@ -240,6 +242,19 @@ def stream_mark(raw):
     return t
 
 
+class unrecorded:
+    """Context: library calls made inside run now but stay out of the command list (one-time set-up such as workspace fills)."""
+
+    def __enter__(self):
+        if _rec is not None:
+            _rec.suspended += 1
+
+    def __exit__(self, *exc):
+        if _rec is not None:
+            _rec.suspended -= 1
+        return False
+
+
 def run_live(fn):
     """Run fn() now; inside a recording it also becomes a LIVE entry of the command list (executed again by every replay, at this
     position): host-side state that changes from step to step (optimizer scalars) and calls outside the library (collectives)."""
@@ -255,7 +270,12 @@ def run_live(fn):
 
 
 def replay(rec):
-    """Enqueue a recorded step again: same kernels, same arguments, same streams and cross-stream dependencies."""
+    """Enqueue a recorded step again: same kernels, same arguments, same streams and cross-stream dependencies.  The list holds the raw
+    streams of the recording; the caller's input copies and the live collectives go to torch's CURRENT stream, so that must be the one the
+    step was recorded under."""
+    if rec.main_stream is not None and not _stream_override and stream_ptr() != rec.main_stream:
+        raise RuntimeError("replay(): the current torch stream differs from the stream the step was recorded on (input copies and "
+                           "collectives would not be ordered with the recorded launches); replay under the recording's stream")
     slots = [0] * rec.nslots
     mark = _lib.ppf_stream_mark
     for c in rec.cmds:
@@ -265,8 +285,13 @@ def replay(rec):
             if rc != 0:
                 raise RuntimeError(f"{c[3]} failed in replay (rc={rc}): {_lib.ppf_last_error().decode()}")
         elif k == 1:
-            slots[c[2]] = mark(c[1])
+            t = mark(c[1])
+            if t < 0:
+                raise RuntimeError(f"ppf_stream_mark failed in replay: {_lib.ppf_last_error().decode()}")
+            slots[c[2]] = t
         elif k == 2:
-            c[1](c[2], slots[c[3]])
+            rc = c[1](c[2], slots[c[3]])
+            if rc != 0:
+                raise RuntimeError(f"ppf_stream_wait_mark failed in replay (rc={rc}): {_lib.ppf_last_error().decode()}")
         else:
             c[1]()

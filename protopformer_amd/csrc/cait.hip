@@ -1073,8 +1073,12 @@ int ppf_th_fwd(const void* qkv, const float* wl, const float* bl, const float* w
         constexpr int HD = decltype(hd)::value, HV = decltype(hv)::value;
         const size_t lds = (size_t)(out ? 2 : 1) * HV * N * HD * 2;
         auto k = th_fwd_kernel<HD, HV>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }
+        static bool attr_set = false;               // one per (HD, HV) instantiation of this generic lambda
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }
+            attr_set = true;
+        }
         hipLaunchKernelGGL(k, dim3(th_groups(N), B), dim3(TH_NTHR), lds, stream, p);
         PPF_LAUNCH_CHECK();
         return 0;
@@ -1095,8 +1099,12 @@ int ppf_th_bwd(const void* qkv, const void* dout, const float* wl, const float* 
         constexpr int HD = decltype(hd)::value, HV = decltype(hv)::value;
         const size_t lds = (size_t)2 * HV * N * HD * 2 + TH_WAVES * (2 * HV * HV + 2 * HV) * sizeof(float);
         auto k = th_bwd_kernel<HD, HV>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }
+        static bool attr_set = false;               // one per (HD, HV) instantiation of this generic lambda
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(talking heads): %s", hipGetErrorString(e)); return (int)e; }
+            attr_set = true;
+        }
         hipLaunchKernelGGL(k, dim3(th_groups(N), B), dim3(TH_NTHR), lds, stream, p);
         PPF_LAUNCH_CHECK();
         return 0;
@@ -1120,8 +1128,12 @@ int ppf_th_grads(const void* qkv, const void* dout, const void* ds16, const void
 #define PPF_TH_GRADS(HDV)                                                                                                                     \
     {                                                                                                                                         \
         auto k = th_grads_kernel<HDV>;                                                                                                        \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(th_grads): %s", hipGetErrorString(e)); return (int)e; }                     \
+        static bool attr_set = false;                                                                                                         \
+        if (!attr_set) {                                                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+            if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(th_grads): %s", hipGetErrorString(e)); return (int)e; }                 \
+            attr_set = true;                                                                                                                  \
+        }                                                                                                                                     \
         hipLaunchKernelGGL(k, dim3(H, B), dim3(TG_NTHR), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)ds16,               \
                            (const bf16_t*)a16, (bf16_t*)dqkv, B, H, N, D, NPK, scale);                                                        \
     }

@@ -88,11 +88,20 @@ struct AdamParams {
     int64_t n; int nseg; Seg seg[MAX_SEGS];
     float beta1, beta2, eps, bc1, bc2_sqrt, ema_decay, grad_scale;
     const float* hyper;          // device-resident step state (PPF_HYPER_* layout) or NULL: then the scalars above are used
+    const float* guard;          // the step's loss (device scalar) or NULL: a non-finite loss skips the whole update ...
+    int* nonfinite;              // ... and raises this flag (engine_proto.py:66-70 exits BEFORE optimizer.step() on such a loss)
 };
 // hyper[0..7] lr per segment, [8..15] weight decay per segment, [16] 1-beta1^t, [17] sqrt(1-beta2^t), [18] gradient scale
 // (1/world), [19] clip factor written by clip_finish_kernel (1 when clipping is off).  Reading them from memory lets a
 // captured HIP graph of the step be replayed with a new step count / learning rate (the host refreshes hyper before a replay).
 __global__ __launch_bounds__(256) void adamw_kernel(AdamParams a) {
+    if (a.guard) {
+        const float loss = *a.guard;
+        if (!(fabsf(loss) <= 3.4028234e38f)) {              // NaN or +-inf: parameters, moments, EMA and the bf16 shadow stay as they are
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.nonfinite = 1;
+            return;
+        }
+    }
     if (a.hyper) {
 #pragma unroll
         for (int s = 0; s < MAX_SEGS; ++s) { a.seg[s].lr = a.hyper[s]; a.seg[s].wd = a.hyper[8 + s]; }
@@ -405,6 +414,7 @@ int ppf_adamw_step(float* p, const float* g, float* m, float* v, float* ema, voi
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     a.ema_decay = ema_decay; a.grad_scale = grad_scale; a.hyper = nullptr;
+    a.guard = nullptr; a.nonfinite = nullptr;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a);
     PPF_LAUNCH_CHECK();
     return 0;
@@ -412,10 +422,14 @@ int ppf_adamw_step(float* p, const float* g, float* m, float* v, float* ema, voi
 
 // The same step with lr / weight decay / bias corrections / gradient scale read from device memory (`hyper`, 20 floats, layout
 // above): nothing step-dependent is baked into the launch, so the call can be captured in a HIP graph and replayed.
-int ppf_adamw_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
-                       const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
-                       hipStream_t stream) {
+// With the reference's per-step "Loss is nan/inf, stopping training" check (tools/engine_proto.py:66-70) folded in without a
+// host synchronisation: `loss` is the step's loss on the device; when it is not finite NOTHING is updated (the reference exits in front
+// of optimizer.step()) and *nonfinite_flag is set to 1 for the host to read at its logging cadence.  loss == NULL: no check.
+int ppf_adamw_step_guarded(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
+                           const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
+                           const float* loss, int* nonfinite_flag, hipStream_t stream) {
     PPF_CHECK_ARG(n > 0 && (n % 4) == 0 && nseg >= 1 && nseg <= MAX_SEGS && hyper, PPF_ERR_ARG, "ppf_adamw_step_dev: bad arguments");
+    PPF_CHECK_ARG((loss == nullptr) == (nonfinite_flag == nullptr), PPF_ERR_ARG, "ppf_adamw_step_guarded: loss and flag go together");
     AdamParams a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.ema = ema; a.p16 = (bf16_t*)p16; a.n = n; a.nseg = nseg;
     for (int s = 0; s < MAX_SEGS; ++s) { a.seg[s].begin = a.seg[s].end = 0; a.seg[s].lr = a.seg[s].wd = 0.f; }
@@ -424,9 +438,17 @@ int ppf_adamw_step_dev(float* p, const float* g, float* m, float* v, float* ema,
         a.seg[s].begin = seg_bounds[s]; a.seg[s].end = seg_bounds[s + 1];
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc1 = a.bc2_sqrt = 1.f; a.ema_decay = ema_decay; a.grad_scale = 1.f; a.hyper = hyper;
+    a.guard = loss; a.nonfinite = nonfinite_flag;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, a);
     PPF_LAUNCH_CHECK();
     return 0;
+}
+
+// The plain form (no loss check).
+int ppf_adamw_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p16, int64_t n, int nseg,
+                       const int64_t* seg_bounds, const float* hyper, float beta1, float beta2, float eps, float ema_decay,
+                       hipStream_t stream) {
+    return ppf_adamw_step_guarded(p, g, m, v, ema, p16, n, nseg, seg_bounds, hyper, beta1, beta2, eps, ema_decay, nullptr, nullptr, stream);
 }
 
 // hyper[0..n) <- host_vals[0..n): the values travel as kernel arguments (read from host memory NOW), so the host may run any

@@ -70,6 +70,8 @@ class FlatAdamW:
         self._clip_partial = None
         self._clip_issued = False                 # ppf_clip_grad_scale wrote hyper[19] for the step about to be applied
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=st.device)
+        # set by the optimizer kernel when a step's loss was NaN / inf (that step is then skipped): engine_proto.py:66-70 without a sync
+        self.nonfinite = ops.zeros((1,), torch.int32, st.device)
 
     # ------------------------------------------------------------------ consistency with the model's flat store
     def _check_store(self):
@@ -108,18 +110,20 @@ class FlatAdamW:
                   self._hyper, self.grad_norm)
         self._clip_issued = True
 
-    def launch_update(self):
+    def launch_update(self, loss_guard=None):
+        """loss_guard: the step's loss (device scalar).  A non-finite loss then skips the update and raises self.nonfinite."""
         st = self.store
-        _lib.call("ppf_adamw_step_dev", st.params, st.grads, self.exp_avg, self.exp_avg_sq, self.ema, st.bf16, st.total, len(self.param_groups),
-                  self._bounds.data_ptr(), self._hyper, self.betas[0], self.betas[1], self.eps, self.ema_decay)
+        _lib.call("ppf_adamw_step_guarded", st.params, st.grads, self.exp_avg, self.exp_avg_sq, self.ema, st.bf16, st.total, len(self.param_groups),
+                  self._bounds.data_ptr(), self._hyper, self.betas[0], self.betas[1], self.eps, self.ema_decay,
+                  loss_guard, self.nonfinite if loss_guard is not None else None)
         st.mark_bf16_written()                    # the kernel re-emitted the bf16 shadow (its transposed copies are now stale)
 
-    def step(self):
+    def step(self, loss_guard=None):
         self._check_store()
         clip = self._clip_issued
         # the step-dependent scalars are read on the host NOW: inside a recorded step (engine.ReplayedTrainStep) this is a live entry
         _lib.run_live(lambda: self._live_refresh(clip))
-        self.launch_update()
+        self.launch_update(loss_guard)
 
     def _live_refresh(self, clip_issued):
         self._clip_issued = clip_issued           # a replay re-runs the recorded clip kernel in front of this point
@@ -392,7 +396,7 @@ def train_one_step(model, criterion, samples, targets, optimizer, epoch=20, ppc_
     _unwrap(model)
     loss, cov, mean = _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss,
                                         grad_sync, check_finite, max_norm)
-    optimizer.step()
+    optimizer.step(loss_guard=loss.detach().reshape(1))
     return loss.detach(), (cov.detach() if cov is not None else None), (mean.detach() if mean is not None else None)
 
 
@@ -441,7 +445,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             loss, cov, mean = _forward_backward(self.model, self.criterion, self.static_in[0], self.static_in[1], opt, **self.kw)
-            opt.launch_update()
+            opt.launch_update(loss.detach().reshape(1))
             self.out = (loss.detach(), cov.detach() if cov is not None else None, mean.detach() if mean is not None else None)
 
     def __call__(self, samples, targets):
@@ -459,9 +463,19 @@ class GraphedTrainStep:
             self.static_in[0].copy_(samples, non_blocking=True)
         if targets.data_ptr() != self.static_in[1].data_ptr():
             self.static_in[1].copy_(targets, non_blocking=True)
+        self._refresh_shadow()
         opt.refresh_hyper()
         self.graph.replay()
         return self.out
+
+    def _refresh_shadow(self):
+        """The frozen step starts from the bf16 weight shadow its own optimizer kernel left behind; the cast of TokensFn.forward is not
+        part of it (the shadow was fresh when the step was captured / recorded).  After model.load_state_dict(), load_checkpoint,
+        broadcast_replica_state or any other edit that invalidated the store, re-cast eagerly in front of the replay (the frozen
+        step's own W^T refresh follows it)."""
+        st = self.optimizer.store
+        if not st.bf16_fresh:
+            st.refresh_bf16()
 
 
 class ReplayedTrainStep(GraphedTrainStep):
@@ -487,8 +501,12 @@ class ReplayedTrainStep(GraphedTrainStep):
             _lib.start_recording()
             try:
                 self.out = train_one_step(self.model, self.criterion, self.static_in[0], self.static_in[1], opt, **self.kw)
-            finally:
-                self.rec = _lib.stop_recording()
+            except BaseException:
+                # a step that raised half-way (out of memory, a kernel error) leaves a truncated list: never keep it
+                _lib.stop_recording()
+                self.static_in, self.out, self.calls = None, None, 0
+                raise
+            self.rec = _lib.stop_recording()
             return self.out
         if samples.shape != self.static_in[0].shape or targets.shape != self.static_in[1].shape or samples.dtype != self.static_in[0].dtype:
             # a batch the list was not recorded for (a short last batch): the eager step, same kernels and streams, nothing recorded
@@ -497,6 +515,7 @@ class ReplayedTrainStep(GraphedTrainStep):
             self.static_in[0].copy_(samples, non_blocking=True)
         if targets.data_ptr() != self.static_in[1].data_ptr():
             self.static_in[1].copy_(targets, non_blocking=True)
+        self._refresh_shadow()
         _lib.replay(self.rec)
         return self.out
 
@@ -524,8 +543,11 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, arg
                                         max_norm=max_norm)
         if it % log_every == 0:
             v = float(loss)
-            if not math.isfinite(v):
-                logger("Loss is {}, stopping training".format(v))
+            # engine_proto.py:66-70 checks every step; here every step's loss is checked ON THE DEVICE by the optimizer kernel (a non-finite
+            # loss skips that update and raises optimizer.nonfinite) and the host reads the flag at the logging cadence: same outcome
+            # (training stops, no update was applied from a bad loss) without a host synchronisation per step
+            if not math.isfinite(v) or int(optimizer.nonfinite) != 0:
+                logger("Loss is {}, stopping training".format(v if not math.isfinite(v) else "non-finite in an earlier step"))
                 sys.exit(1)
             logger(f"Epoch: [{epoch}] it {it} loss {v:.4f} lr {optimizer.param_groups[0]['lr']:.6f}")
             total += v

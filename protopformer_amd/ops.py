@@ -21,12 +21,15 @@ def _workspace(device, nbytes):
     key = (device, _lib.stream_ptr())
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _RETIRED_WS.append(buf)           # a side stream may still be using it (see _gemm_workspace)
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
         _WORKSPACE[key] = buf
     return buf
 
 
 _GEMM_WS = {}
+_RETIRED_WS = []
 
 
 def _gemm_workspace(device, nbytes):
@@ -35,7 +38,14 @@ def _gemm_workspace(device, nbytes):
     key = (device, _lib.stream_ptr())
     buf = _GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        # the fill must run on the CONSUMER stream (the weight-gradient lane redirects only the library's launches, torch.zeros would
+        # fill on torch's current stream, unordered against the split-K GEMM that follows on the lane); a buffer that is outgrown stays
+        # allocated: the lane may still be reading it and the allocator knows nothing of that stream
+        if buf is not None:
+            _RETIRED_WS.append(buf)
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        with _lib.unrecorded():
+            _lib.call("ppf_memset_zero", buf, buf.numel())
         _GEMM_WS[key] = buf
     return buf
 

@@ -367,3 +367,53 @@ def test_replayed_step_equals_eager_step(arch):
     assert math.isfinite(l_b) and math.isfinite(l_b2) and opt_a.step_count == opt_b.step_count == 8
     if arch == "cait" and strict:                 # DropPath off: the interleaved eager / replayed steps see the same (no) draws
         assert l_a == l_b and l_a2 == l_b2 and torch.equal(a.flat_store().params, b.flat_store().params)
+
+
+@pytest.mark.parametrize("kind", ["replayed", "graphed"])
+def test_frozen_step_recasts_the_shadow_after_load_state_dict(kind):
+    """A recorded / captured step does not contain the fp32 -> bf16 weight cast (the shadow was fresh when it was frozen).  After
+    model.load_state_dict() between two steps the next frozen step must run on the NEW weights, like the eager step does."""
+    from protopformer_amd.engine import FlatAdamW, GraphedTrainStep, ReplayedTrainStep, train_one_step
+    from protopformer_amd.protopformer import CrossEntropyLoss
+    sd, cfg, z = micro("micro_deit.npz")
+    img, label = torch.from_numpy(z["img"]).cuda(), torch.from_numpy(z["label"]).cuda()
+    crit = CrossEntropyLoss()
+    sd2 = {k: (v * 1.25 if v.dtype.is_floating_point and "last_layer" not in k and k != "ones" else v) for k, v in sd.items()}
+    a = build_micro(cfg, sd).train(); opt_a = FlatAdamW(a, weight_decay=0.05)
+    b = build_micro(cfg, sd).train(); opt_b = FlatAdamW(b, weight_decay=0.05)
+    step = (ReplayedTrainStep if kind == "replayed" else GraphedTrainStep)(b, crit, opt_b, epoch=20, warmup=1)
+    for _ in range(3):                                   # warm-up, freeze, one replay
+        la = float(train_one_step(a, crit, img, label, opt_a, epoch=20)[0]); lb = float(step(img, label)[0])
+        assert la == lb
+    a.load_state_dict(sd2); b.load_state_dict(sd2)
+    assert not b.flat_store().bf16_fresh
+    la = float(train_one_step(a, crit, img, label, opt_a, epoch=20)[0]); lb = float(step(img, label)[0])
+    torch.cuda.synchronize()
+    assert la == lb, (la, lb)
+    assert torch.equal(a.flat_store().params, b.flat_store().params)
+
+
+def test_nonfinite_loss_skips_the_update_and_raises_the_flag():
+    """tools/engine_proto.py:66-70 (exit in front of optimizer.step() when the loss is NaN / inf), evaluated on the device every step: the
+    optimizer kernel leaves parameters, moments, EMA and the bf16 shadow untouched and raises optimizer.nonfinite; train_one_epoch reads
+    the flag at its logging cadence and stops."""
+    from protopformer_amd.engine import FlatAdamW, train_one_epoch, train_one_step
+    from protopformer_amd.protopformer import CrossEntropyLoss
+    sd, cfg, z = micro("micro_deit.npz")
+    img, label = torch.from_numpy(z["img"]).cuda(), torch.from_numpy(z["label"]).cuda()
+    crit = CrossEntropyLoss()
+    m = build_micro(cfg, sd).train(); opt = FlatAdamW(m, weight_decay=0.05, ema_decay=0.999)
+    train_one_step(m, crit, img, label, opt, epoch=20)
+    assert int(opt.nonfinite) == 0
+    st = m.flat_store()
+    before = (st.params.clone(), st.bf16.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.ema.clone())
+    bad = img.clone(); bad[0, 0, 0, 0] = float("nan")
+    loss, _, _ = train_one_step(m, crit, bad, label, opt, epoch=20)
+    assert not math.isfinite(float(loss)) and int(opt.nonfinite) == 1
+    after = (st.params, st.bf16, opt.exp_avg, opt.exp_avg_sq, opt.ema)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(before, after))
+    # the epoch loop stops at its next log read, even if that step's own loss is finite again
+    logs = []
+    with pytest.raises(SystemExit):
+        train_one_epoch(m, crit, [(img, label)] * 3, opt, "cuda", epoch=20, log_every=2, logger=logs.append)
+    assert any("stopping training" in s for s in logs)
