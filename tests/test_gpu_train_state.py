@@ -407,8 +407,10 @@ def test_nonfinite_loss_skips_the_update_and_raises_the_flag():
     assert int(opt.nonfinite) == 0
     st = m.flat_store()
     before = (st.params.clone(), st.bf16.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.ema.clone())
-    bad = img.clone(); bad[0, 0, 0, 0] = float("nan")
-    loss, _, _ = train_one_step(m, crit, bad, label, opt, epoch=20)
+    good = m.last_layer.weight.data.clone()
+    m.last_layer.weight.data.fill_(float("nan"))              # frozen class-connection weights: logits, hence the loss, become NaN
+    loss, _, _ = train_one_step(m, crit, img, label, opt, epoch=20)
+    m.last_layer.weight.data.copy_(good)
     assert not math.isfinite(float(loss)) and int(opt.nonfinite) == 1
     after = (st.params, st.bf16, opt.exp_avg, opt.exp_avg_sq, opt.ema)
     assert all(torch.equal(a_, b_) for a_, b_ in zip(before, after))
