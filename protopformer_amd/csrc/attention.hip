@@ -40,6 +40,7 @@ struct AttnParams {
     int self_keep;         // 1: a masked query still attends to itself (DeiT); 0: CaiT class attention
     float scale;
     float eps_c;           // eps / N_ref: the +eps/N term of the policy softmax; N_ref = tokens BEFORE reservation (compacted blocks pass it)
+    int ko;                // measurement only (PPF_ATTN_KO bit mask, results wrong): phases of attn_bwd_stream_kernel knocked out
 };
 
 __device__ __forceinline__ int kswz(int row) {
@@ -865,6 +866,279 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_onepass_kernel(cons
     }
 }
 
+// ------------------------------------------------------------------------------------------- backward, one pass, streaming (round 4)
+// The pair decomposition of attn_bwd_onepass_kernel (wave w owns key tile w, K / V fragments and dK / dV accumulators in registers,
+// dQ accumulated per query tile in LDS by exclusive read-modify-write in a rotated order), rebuilt around what the knock-outs of that
+// kernel showed (profiles/r4_attn_bwd.txt): its phases ADD -- 33 us fixed + 20 staging + 85 pair loop + 48 stores of 163 us, and inside
+// the pair loop softmax arithmetic (32 us), dK / dV products (17), dQ read-modify-write (11) and the rest (25) add as well, because
+// one 147 KiB workgroup per CU leaves nobody to fill a phase and a barrier per step keeps all waves in the same phase.
+//   * PERSISTENT workgroups walk items (batch, head) = blockIdx.x, blockIdx.x + gridDim.x, ...: the moment the last pair of item i is
+//     done every wave issues item i + 1's loads and only then writes item i's results -- loads and stores overlap each other.
+//   * Q and dO images (the only operands every wave needs) arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction,
+//     chunk swizzle on the SOURCE address); K / V / O rows of the wave's own 32 keys / queries go straight to registers; K^T fragments
+//     come from a transposed read of the wave's own 4 KiB scratch tile.  No K / V / O images, no staging registers.  Results leave
+//     through the wave's OWN scratch tile as 16-byte row-contiguous stores, without any workgroup barrier.
+//   * A pair is split into P1 (S, dP products; softmax + dS arithmetic; dS^T to the scratch tile) and P2 (dK, dV products; dQ product +
+//     read-modify-write).  Waves 0-3 and waves 4-6 -- the two waves that share a SIMD are one of each -- run HALF A STEP APART: while
+//     one does the VALU-heavy P1 its SIMD partner does the MFMA / LDS-heavy P2.  2 NT + 1 half-steps per item, one barrier each; the
+//     tiles under read-modify-write in a half-step belong to one group only and are distinct (rotation), and the order in which the key
+//     tiles reach a query tile is fixed by the schedule: bit-identical from run to run, no atomics.
+//   * 1/sum of the softmax is folded into the exponent (row statistic m' = m log2(e) - log2(1/sum)); the key-keep factor is applied only
+//     where a key can be masked (policy given, or the tile holding the padded keys).
+// Padded queries (rows >= N of the images repeat row N - 1, finite) are neutralised by their statistics: m' = +3e38 -> exp2 -> 0, eps
+// term = 0.  Padded keys: keep = 0 as before.
+template <int HD, int NT>
+struct StreamLds {
+    static constexpr int TILE = NT * 32 * 128, DT = (HD + 31) / 32, DQT = DT * 4 * 64 * 4;
+    static constexpr int BYTES = 2 * TILE + NT * DQT * 4 + NT * 4096 + 3 * NT * 32 * 4;
+};
+template <int HD, int NT>
+__global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnParams p, const int nitems) {
+    static_assert(HD == 64, "128-byte rows: one full line per (token, head)");
+    constexpr int TILE = NT * 32 * 128;
+    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
+    constexpr int DQT = DT * 4 * 64 * 4;                        // floats of one query tile's dQ accumulator: [dt][g][lane][4]
+    constexpr int PPW = 8;                                      // 1 KiB pieces per wave: 4 of the Q image, 4 of the dO image (4 NT each)
+    constexpr int G0 = NT;                                     // waves [0, G0) lead, waves [G0, NT) run half a step behind (measured: no gain, off)
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* tQ = lds;
+    unsigned char* tO = lds + TILE;                            // dO
+    float* dqacc = reinterpret_cast<float*>(lds + 2 * TILE);
+    unsigned char* scr_all = lds + 2 * TILE + NT * DQT * 4;
+    float* st_m = reinterpret_cast<float*>(scr_all + NT * 4096);
+    float* st_d = st_m + NT * 32;
+    float* st_cz = st_d + NT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, H = p.H;
+    const int r0 = wave * 32;                      // this wave's key tile (and the query tile whose statistics / dQ rows it handles)
+    const bool active = r0 < N;
+    const bool lag = wave >= G0;
+    const bool masked = p.policy != nullptr || r0 + 32 > N;      // wave-uniform: some key of this tile may carry keep = 0
+    const int row = r0 + l31, rc = min(row, N - 1);
+    unsigned char* scr = scr_all + wave * 4096;
+    const float sc2 = p.scale * LOG2E;
+
+    // LDS-DMA pieces of this wave: piece j = wave + NT i, i < 4: rows 8 j .. 8 j + 7 of the Q image, i >= 4: of the dO image; lane l
+    // carries row (l >> 3), LDS chunk slot (l & 7) whose SOURCE chunk is slot ^ kswz(row).  (Offsets are recomputed per item: eight
+    // more live registers across the pair loop are eight spills.)
+    auto issue_images = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        const unsigned char* qb = reinterpret_cast<const unsigned char*>(p.qkv + (size_t)b * N * p.ld + h * HD);
+        const unsigned char* ob = reinterpret_cast<const unsigned char*>(p.dout + (size_t)b * N * p.D + h * HD);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int j = wave + NT * (i & 3), r = j * 8 + (lane >> 3);
+            const int off = min(r, N - 1) * (i < 4 ? p.ld : p.D) * 2 + (((lane & 7) ^ kswz(r)) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_void*)((i < 4 ? qb : ob) + off), (lds_void*)(lds + (i < 4 ? 0 : TILE) + j * 1024), 16, 0, 0);
+        }
+    };
+    // rows of the wave's own tile, MFMA fragment layout (lane -> row l31, 8 values at d = 16 ks + 8 hh): K, V (key tile), O (query tile,
+    // for delta = rowsum(dO * O)) and the softmax statistics of the own query rows
+    bf16x8 kf[KS], vf[KS];
+    auto load_rows = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        const bf16_t* base = p.qkv + ((size_t)b * N + rc) * p.ld + h * HD + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(base + p.D + 16 * ks);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * p.D + 16 * ks);
+        }
+    };
+    int item = blockIdx.x;
+    if (item < nitems) { issue_images(item); load_rows(item); }
+#pragma unroll 1
+    for (; item < nitems; item += gridDim.x) {
+        const int b = item / H, h = item - b * H;
+        // ---- own query rows: O (for delta = rowsum(dO * O)) and the softmax statistics; consumed behind the wait for the images
+        // (prefetching them one item ahead costs 19 more live registers = spills: measured slower)
+        bf16x8 ovf[KS];
+        {
+            const bf16_t* orow = p.out + ((size_t)b * N + rc) * p.D + h * HD + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+        }
+        const size_t si = ((size_t)b * H + h) * N + rc;
+        const float s_m = p.rowmax[si], s_z = p.zinv[si];
+        const float s_pol = p.policy ? p.policy[(size_t)b * N + rc] : 1.0f;
+        // ---- own key tile: K^T fragments through the scratch tile; zeroed dQ accumulator and statistics of the own query tile
+        bf16x8 ktr[2][DT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(scr + row_off(l31, ks * 2 + hh)) = kf[ks];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) ktr[st][dt] = frag_tr(scr, 16 * st, dt * 32, lane);
+        {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4* qz = reinterpret_cast<float4*>(dqacc + wave * DQT) + lane;
+#pragma unroll
+            for (int i = 0; i < DQT / 256; ++i) qz[i * 64] = z4;
+        }
+        const float keep_key = row < N ? s_pol : 0.f;
+        if (hh == 0) {
+            const bool real = row < N;
+            // p = exp2(s scale log2e - m'), m' = m log2e - log2(1 / (sum + eps)); padded queries: m' = 3e38 -> p = 0 whatever their scores
+            st_m[row] = real ? s_m * LOG2E - __builtin_amdgcn_logf(s_z) : 3.0e38f;
+            st_cz[row] = real ? p.eps_c * s_z : 0.f;                    // the eps / N term of the policy softmax, per query
+        }
+        // ---- images of this item have landed (this wave's pieces: vmcnt; the others': barrier); statistics and zeroes are visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // delta of the own query tile from the dO image: the first pair of every wave is its OWN query tile, the other tiles' deltas are
+        // read behind at least one more barrier
+        {
+            float dl = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 dof = frag_rows(tO, r0, ks, lane);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)dof[e] * (float)ovf[ks][e];
+            }
+            dl += __shfl_xor(dl, 32, 64);
+            if (hh == 0) st_d[row] = row < N ? dl : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        f32x16 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+        bf16x8 dsf[2], pf[2];                           // dS and P of the pair between its two halves (bf16: MFMA operands of P2)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { dsf[st] = kf[0]; pf[st] = kf[0]; }
+
+        // P1 of step i: scores, dP, softmax, dS
+        auto p1 = [&](int i) {
+            int t = wave + i;
+            if (t >= NT) t -= NT;
+            f32x16 s, g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tQ, t * 32, ks, lane), kf[ks], s, 0, 0, 0);   // [q][key]
+                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tO, t * 32, ks, lane), vf[ks], g, 0, 0, 0);   // dO.V^T
+            }
+            // softmax + dS on the packed fp32 pipe (two queries per instruction).  Only the diagonal pair (t == own tile) contains
+            // "a masked query still attends to itself" positions.
+            const bool diag = masked && t == wave && p.self_keep;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int qq0 = t * 32 + 8 * gg + 4 * hh;
+                const float4 m4 = *reinterpret_cast<const float4*>(st_m + qq0), d4 = *reinterpret_cast<const float4*>(st_d + qq0),
+                             c4 = *reinterpret_cast<const float4*>(st_cz + qq0);
+                const ppf_float2 mm[2] = {{m4.x, m4.y}, {m4.z, m4.w}}, dd[2] = {{d4.x, d4.y}, {d4.z, d4.w}}, cz[2] = {{c4.x, c4.y}, {c4.z, c4.w}};
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int r = 4 * gg + 2 * jp;
+                    const ppf_float2 sv = {s[r], s[r + 1]}, gv = {g[r], g[r + 1]};
+                    const ppf_float2 x = sv * sc2 - mm[jp];
+                    ppf_float2 pt; pt.x = __builtin_amdgcn_exp2f(x.x); pt.y = __builtin_amdgcn_exp2f(x.y);
+                    if (masked) {
+                        ppf_float2 kk = {keep_key, keep_key};
+                        if (diag) {
+                            if (qq0 + 2 * jp == row) kk.x = 1.0f;
+                            if (qq0 + 2 * jp + 1 == row) kk.y = 1.0f;
+                        }
+                        pt = pt * kk;
+                    }
+                    const ppf_float2 ds = pt * (gv - dd[jp]), po = pt + cz[jp];
+                    s[r] = ds.x; s[r + 1] = ds.y;                                  // dS[q][key]
+                    g[r] = po.x; g[r + 1] = po.y;                                  // out[q][key]
+                }
+                // dS as bf16 [key][query] for the transposed read of P2: this lane's key row, queries 8 gg + 4 hh .. + 3
+                *reinterpret_cast<uint2*>(scr + row_off(l31, gg) + 8 * hh) =
+                    make_uint2(pack_bf16x2(s[4 * gg], s[4 * gg + 1]), pack_bf16x2(s[4 * gg + 2], s[4 * gg + 3]));
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) { dsf[st] = pack8(s, 8 * st); pf[st] = pack8(g, 8 * st); }
+        };
+        // P2 of step i: dK, dV, dQ
+        auto p2 = [&](int i) {
+            int t = wave + i;
+            if (t >= NT) t -= NT;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, t * 32 + 16 * st, dt * 32, lane), dsf[st], dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tO, t * 32 + 16 * st, dt * 32, lane), pf[st], dv[dt], 0, 0, 0);
+                }
+            // dQ^T[d][q] of this pair: K^T (registers) x dS^T (scratch, keys in the contraction slots, queries in the lanes)
+            float* qa = dqacc + t * DQT + lane * 4;
+            f32x16 dq[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 v = *reinterpret_cast<const float4*>(qa + (dt * 4 + gq) * 256);
+                    dq[dt][4 * gq] = v.x; dq[dt][4 * gq + 1] = v.y; dq[dt][4 * gq + 2] = v.z; dq[dt][4 * gq + 3] = v.w;
+                }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 dst = frag_tr(scr, 16 * st, 0, lane);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[st][dt], dst, dq[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<float4*>(qa + (dt * 4 + gq) * 256) = make_float4(dq[dt][4 * gq], dq[dt][4 * gq + 1], dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+        };
+        // Both groups run the same instruction stream "P1(i); barrier; P2(i); barrier"; the lagging group enters it one barrier later and
+        // the leading group waits one barrier longer at the end, so between two barriers one group is in P1 and the other in P2.
+        // (s_barrier counts arrivals of the workgroup's waves: the call sites need not be the same, the COUNT per wave is: 2 NT + 1.)
+        if (lag) __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < NT; ++i) {
+            if (active && !(p.ko & 1)) p1(i);
+            if constexpr (G0 < NT) __syncthreads();
+            if (active && !(p.ko & 1)) p2(i);
+            __syncthreads();
+        }
+        if (!lag) __syncthreads();
+        // ---- every wave is past the last pair: the images are dead.  The next item's loads go out first, this item's results after them.
+        const int nxt = item + gridDim.x;
+        if (nxt < nitems && !(p.ko & 4)) { issue_images(nxt); load_rows(nxt); }
+        if (active && !(p.ko & 2)) {
+            bf16_t* dst = p.dqkv + ((size_t)b * N + r0) * p.ld + h * HD;
+            const float* qa = dqacc + wave * DQT + lane * 4;
+#pragma unroll
+            for (int which = 0; which < 3; ++which) {              // 0: dQ (own query tile), 1: dK, 2: dV (own key tile)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v0, v1, v2, v3;
+                        if (which == 0) { const float4 q4 = *reinterpret_cast<const float4*>(qa + (dt * 4 + g) * 256); v0 = q4.x * p.scale; v1 = q4.y * p.scale; v2 = q4.z * p.scale; v3 = q4.w * p.scale; }
+                        else if (which == 1) { v0 = dk[dt][4 * g] * p.scale; v1 = dk[dt][4 * g + 1] * p.scale; v2 = dk[dt][4 * g + 2] * p.scale; v3 = dk[dt][4 * g + 3] * p.scale; }
+                        else { v0 = dv[dt][4 * g]; v1 = dv[dt][4 * g + 1]; v2 = dv[dt][4 * g + 2]; v3 = dv[dt][4 * g + 3]; }
+                        *reinterpret_cast<uint2*>(scr + row_off(l31, dt * 4 + g) + 8 * hh) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = (lane >> 3) + 8 * it, cc = lane & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(scr + row_off(r, cc));
+                    if (r0 + r < N) *reinterpret_cast<uint4*>(dst + (size_t)r * p.ld + which * p.D + cc * 8) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <typename F>
 int dispatch(int hd, int N, const char* who, F&& f) {
     const int nt = (N + 31) / 32;
@@ -889,6 +1163,8 @@ int fill(AttnParams& p, const void* qkv, int B, int H, int N, int D, const float
     p = AttnParams();
     p.qkv = (const bf16_t*)qkv; p.ld = 3 * D; p.policy = policy; p.rowmax = rowmax; p.zinv = zinv; p.B = B; p.H = H; p.N = N; p.D = D;
     p.self_keep = self_keep; p.scale = 1.0f / sqrtf((float)(D / H));
+    static const int ko = getenv("PPF_ATTN_KO") ? atoi(getenv("PPF_ATTN_KO")) : 0;
+    p.ko = ko;
     p.eps_c = SOFTMAX_EPS / (float)(eps_n > 0 ? eps_n : N);
     return 0;
 }
@@ -971,11 +1247,37 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
-    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 1;
+    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 2;
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
         constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
+        if constexpr (HDv == 64) {
+            if (fused >= 2) {   // the streaming form of the one-pass kernel (default)
+                constexpr int lds_bytes = StreamLds<HDv, NTv>::BYTES;
+                auto kern = attn_bwd_stream_kernel<HDv, NTv>;
+                static bool attr_set = false;
+                static int slots = 0;                          // workgroups the chip holds at once: CUs x (LDS- and wave-limited) per CU
+                if (!attr_set) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                    if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+                    int dev = 0, cus = 256;
+                    (void)hipGetDevice(&dev);
+                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                    int per = (160 * 1024) / lds_bytes;
+                    if (per > 8 / NTv) per = 8 / NTv;           // <= 256 VGPRs: two waves per SIMD
+                    if (per < 1) per = 1;
+                    slots = cus * per;
+                    attr_set = true;
+                }
+                // every workgroup walks the same number of items (the launch lasts as long as its longest walk): 384 items on 256 slots
+                // take two rounds either way, 192 workgroups leave the other CUs to the side stream
+                const int nitems = B * H, rounds = (nitems + slots - 1) / slots, grid = (nitems + rounds - 1) / rounds;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv * 64), lds_bytes, stream, p, nitems);
+                PPF_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if (fused) {            // one pass over the (query tile, key tile) pairs (PPF_ATTN_BWD_FUSED=0: the two-kernel form dq + dkv)
             constexpr int lds_bytes = OnePassLds<HDv, NTv>::BYTES;
             auto kern = attn_bwd_onepass_kernel<HDv, NTv>;

@@ -547,6 +547,8 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) 
     const long long tall_tiles = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * splitk * nbatch;
     // measured (profiles/r1_gemm_tile_ab.txt): the 256x128 tile is 5-30 % slower at every shape of this model -> opt-in only
     (void)tall_tiles;
+    // (round 4: the 256x128 form was also tried for the weight gradient with 1536 output rows, same and doubled K slices: 12.2k / 13.4k
+    // img/s against 15.6k -- profiles/r4_wgrad_tiles.txt)
     const bool tall = forced == 4;
     if (tall) return launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch);
     // PPF_GEMM_PD=3: three K tiles in flight for the long-contraction weight gradients (measured equal to one tile ahead: the kernel is

@@ -129,3 +129,28 @@ def test_attn_bwd_bit_identical_runs():
     for _ in range(5):
         again = ops.attn_bwd(qkv, out, dout, rowmax, zinv, B, H, N, D, policy=pol)
         assert torch.equal(first.view(torch.int16), again.view(torch.int16))
+
+
+def test_attn_bwd_streaming_many_items_per_workgroup():
+    """More (batch, head) items than the chip holds workgroups: the persistent backward kernel walks several items per workgroup, prefetching
+    item i + 1 (LDS-DMA images, K / V rows) under the stores of item i.  Against the fp32 oracle on every item, and bit-identical twice."""
+    from protopformer_amd import ops
+    B, H, N, D = 48, 6, 197, 384                       # 288 items on <= 256 one-workgroup-per-CU slots
+    hd = D // H
+    qkv = _qkv(B, N, D, 31, 1.2)
+    dout = torch.randn(B * N, D, generator=torch.Generator().manual_seed(32)).bfloat16()
+    pol = _policy(B, N, 60, 9)
+    x = qkv.float().clone().requires_grad_(True)
+    t = x.reshape(B, N, 3, H, hd)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    p = O.policy_softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, pol, self_keep=True)
+    (p @ v).transpose(1, 2).reshape(B * N, D).backward(dout.float())
+    ref = x.grad
+    out, rowmax, zinv = ops.attn_fwd(qkv.cuda(), B, H, N, D, policy=pol.cuda())
+    got = ops.attn_bwd(qkv.cuda(), out, dout.cuda(), rowmax, zinv, B, H, N, D, policy=pol.cuda())
+    again = ops.attn_bwd(qkv.cuda(), out, dout.cuda(), rowmax, zinv, B, H, N, D, policy=pol.cuda())
+    assert torch.equal(got.view(torch.int16), again.view(torch.int16))
+    dqkv = got.float().cpu()
+    scale = float(ref.abs().max())
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert_close(dqkv[:, sl], ref[:, sl], rtol=2e-2, atol=1.5e-2 * scale, what=name)
