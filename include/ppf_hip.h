@@ -51,9 +51,11 @@ int ppf_stream_wait_mark(ppf_stream_t stream, int64_t ticket);
  *                                                add_on_layers 1x1 conv (protopformer.py:111-114,171-172)
  *   dgrad    dx = dy W                    (0,1)  autograd of the above
  *   wgrad    dW += dy^T x (+ db)          (1,1)  split over kc, fp32 atomics into C, colsum[m] += sum_kc A(m,kc)
- * epi: 0 bf16 out | 1 f32 out | 2 bias+GELU(erf): C=gelu(pre) bf16, aux_out=gelu'(pre) bf16 (saved for backward) | 3 sigmoid f32 out |
+ * epi: 0 bf16 out | 1 f32 out | 2 bias+GELU(erf): C=gelu(pre) bf16, aux_out=gelu'(pre) as ONE BYTE per element (saved for backward:
+ *        code q = rint((d + 0.13) * 255 / 1.26), |error| <= 2.5e-3) | 3 sigmoid f32 out |
  *      4 residual: C f32 = res + rowscale[m/rows_per_group]*colscale[n]*(acc+bias)  (DropPath deit:79-80, LayerScale
- *        cait:156-157), optional aux_out = raw branch output bf16 | 5 dGELU: C bf16 = acc * aux_in (aux_in = gelu' from epi 2) | 6 atomic f32. */
+ *        cait:156-157), optional aux_out = raw branch output bf16 | 5 dGELU: C bf16 = acc * aux_in (aux_in = the gelu' codes of epi 2) | 6 atomic f32.
+ * ldaux counts ELEMENTS of the aux tensor (bytes for epi 2 / 5, bf16 for epi 4). */
 int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                   int trans_b, int epi, const float* bias, const float* res, int ldres, const float* rowscale,
                   int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,

@@ -146,7 +146,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         else:
             x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
             n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
-        h = torch.empty((M, hid), dtype=torch.bfloat16, device=x.device)
+        h = torch.empty((M, hid), dtype=torch.uint8, device=x.device)            # gelu'(pre-activation), 8-bit codes (csrc/gemm_common.h)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
         if fused:
             # the next block's norm1 rides on this block's fc2 product, unless the token gather of the reservation comes in between

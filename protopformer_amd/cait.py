@@ -163,7 +163,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
             x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=N,
                           colscale=blk.gamma_1, aux_out=raw1)
             n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
-        h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
+        h = torch.empty((M, blk.mlp.fc1.out_features), dtype=torch.uint8, device=x.device)     # gelu'(pre-activation), 8-bit codes
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
         raw2 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         nxt = feats.blocks[i + 1] if i + 1 < depth else None
@@ -205,7 +205,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         raw1 = torch.empty((B, D), dtype=torch.bfloat16, device=x.device) if save else None
         cls1 = ops.gemm(out, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=cls, colscale=blk.gamma_1, aux_out=raw1)
         n2, mean2, rstd2 = ops.layernorm_fwd(cls1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
-        h = torch.empty((B, blk.mlp.fc1.out_features), dtype=torch.bfloat16, device=x.device)
+        h = torch.empty((B, blk.mlp.fc1.out_features), dtype=torch.uint8, device=x.device)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
         raw2 = torch.empty((B, D), dtype=torch.bfloat16, device=x.device) if save else None
         cls2 = ops.gemm(g, store.w16(blk.mlp.fc2.weight), epi=EPI_RESID, bias=blk.mlp.fc2.bias, res=cls1, colscale=blk.gamma_2, aux_out=raw2)

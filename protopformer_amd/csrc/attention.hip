@@ -256,9 +256,16 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     float* pol = reinterpret_cast<float*>(lds16 + 2 * BUF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l15 = lane & 15;
-    const int b = blockIdx.y, N = p.N;
-    // the sample's 16-query blocks are dealt out evenly to the workgroups of this sample (13 blocks on 2 workgroups: 7 + 6)
-    const int nb = (N + 15) / 16, nw = gridDim.x, per = nb / nw, rem = nb % nw, x = blockIdx.x;
+    const int N = p.N;
+    // the sample's 16-query blocks are dealt out evenly to the workgroups of this sample (13 blocks on 2 workgroups: 7 + 6).  The two
+    // workgroups of a sample read the same K / V: they are placed on the SAME XCD (dispatch ids L and L + 8; observed placement L % 8,
+    // speed only) so that the second read is served by that XCD's L2 instead of crossing the fabric again
+    int b = blockIdx.y, x = blockIdx.x;
+    if (gridDim.x == 2 && (gridDim.y & 7) == 0 && !(p.ko & 64)) {
+        const int L = blockIdx.x + 2 * blockIdx.y, r = L & 15;
+        b = (L >> 4) * 8 + (r & 7); x = r >> 3;
+    }
+    const int nb = (N + 15) / 16, nw = gridDim.x, per = nb / nw, rem = nb % nw;
     const int first = x * per + min(x, rem), cnt = per + (x < rem ? 1 : 0);
     const bool active = wave < cnt;
     const int q = (first + wave) * 16 + l15, qc = min(q, N - 1);

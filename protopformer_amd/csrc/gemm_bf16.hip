@@ -664,7 +664,7 @@ size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 // Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
-// epi: 0 bf16 out, 1 f32 out, 2 bias+GELU (C = gelu(pre) bf16, aux_out = gelu'(pre) bf16), 3 sigmoid f32 out,
+// epi: 0 bf16 out, 1 f32 out, 2 bias+GELU (C = gelu(pre) bf16, aux_out = gelu'(pre) as 8-bit codes, gemm_common.h gelu8_*), 3 sigmoid f32 out,
 //      4 residual (C f32 = res + rowscale*colscale*(acc+bias), optional aux_out raw bf16), 5 dGELU (C bf16 = acc*aux_in, aux_in = the gelu' written by epi 2),
 //      6 f32 accumulate into C (C += ...; split over the contraction; optional colsum[m] += sum_kc A(m,kc) when trans_a).
 //        With a workspace of ppf_gemm_workspace_bytes(M,N,K) the slices write partial tiles that a second kernel reduces in a

@@ -15,8 +15,8 @@ struct GemmParams {
     const float* rowscale;   // EPI_RESID: per-sample scale, index m / rows_per_group (DropPath), or null
     int rows_per_group;
     const float* colscale;   // EPI_RESID: per-column scale (LayerScale gamma), or null
-    const bf16_t* aux_in;    // EPI_DGELU: gelu'(pre-activation) [M][ldaux], as written by EPI_GELU
-    bf16_t* aux_out;         // EPI_GELU: gelu'(pre-activation) out; EPI_RESID: raw branch output (optional)
+    const bf16_t* aux_in;    // EPI_DGELU: gelu'(pre-activation) [M][ldaux] as 8-bit codes (gelu8_*), as written by EPI_GELU
+    bf16_t* aux_out;         // EPI_GELU: gelu'(pre-activation) out, one BYTE per element; EPI_RESID: raw branch output bf16 (optional)
     int ldaux;
     float* colsum;           // EPI_ATOMIC + TA: sum over kc of A(m,kc) accumulated atomically into colsum[m]
     float* ws;               // EPI_PARTIAL: split-K workspace [nsplit][M*N (+M)] fp32 partial tiles (+ partial column sums)
@@ -31,6 +31,26 @@ struct GemmParams {
     unsigned* counters;      // EPI_PARTIAL: per-output-tile arrival counters (zero between calls): the LAST slice to arrive adds the tile's
                              // partials up in slice order and accumulates them into C (no separate reduce launch); null: splitk_reduce_kernel
 };
+
+// gelu'(x) of the erf GELU lies in [-0.1290, 1.1290]: it is saved for the backward pass as an 8-bit linear code (round 4):
+// q = rint((d - LO) / STEP), d' = LO + q STEP, |d' - d| <= STEP / 2 = 2.5e-3 -- the size of the bf16 rounding of a value in [0.5, 1.13]
+// (2.0e-3 / 3.9e-3), at half the bytes: 155 -> 77.5 MB written by fc1 and read by the fc2 input-gradient GEMM per deit_small layer.
+constexpr float GELU8_LO = -0.13f, GELU8_STEP = 1.26f / 255.0f, GELU8_INV = 255.0f / 1.26f;
+__device__ __forceinline__ uint32_t gelu8_pack4(float a, float b, float c, float d) {
+    // v_cvt_pk_u8_f32 rounds to nearest and saturates to [0, 255]
+    uint32_t r = 0;
+    r = __builtin_amdgcn_cvt_pk_u8_f32((a - GELU8_LO) * GELU8_INV, 0, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32((b - GELU8_LO) * GELU8_INV, 1, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32((c - GELU8_LO) * GELU8_INV, 2, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32((d - GELU8_LO) * GELU8_INV, 3, r);
+    return r;
+}
+__device__ __forceinline__ void gelu8_unpack4(uint32_t q, float (&d)[4]) {
+    d[0] = (float)(q & 0xffu) * GELU8_STEP + GELU8_LO;
+    d[1] = (float)((q >> 8) & 0xffu) * GELU8_STEP + GELU8_LO;
+    d[2] = (float)((q >> 16) & 0xffu) * GELU8_STEP + GELU8_LO;
+    d[3] = (float)((q >> 24) & 0xffu) * GELU8_STEP + GELU8_LO;
+}
 
 // The fused epilogues work on 4 consecutive columns of one output row.  On gfx9 loads and stores share the vmcnt counter and
 // the compiler waits vmcnt(0) before it uses a loaded value whenever stores are pending too -- a load between two stores makes
@@ -63,9 +83,8 @@ __device__ __forceinline__ EpiRow epi_load_row(const GemmParams& p, int m, int n
         }
     } else if constexpr (EPI == EPI_DGELU) {
         if (ok) {                                 // read once, 10 ms after it was written: streaming load
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p.aux_in + (size_t)m * p.ldaux + n0));
-            r.aux = make_uint2(t.x, t.y);
+            const uint32_t t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(p.aux_in) + (size_t)m * p.ldaux + n0));
+            r.aux = make_uint2(t, 0);
         }
     }
     return r;
@@ -106,9 +125,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
         gelu_erf_both2(ppf_float2{v[2], v[3]}, g23, d23);
         const float g[4] = {g01.x, g01.y, g23.x, g23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
         // gelu' is not read again before the backward pass: streaming (non-temporal) store, keeps L2 / MALL for the operands
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 dv = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
-        __builtin_nontemporal_store(dv, reinterpret_cast<u32x2*>(p.aux_out + (size_t)m * p.ldaux + n0));
+        __builtin_nontemporal_store(gelu8_pack4(d[0], d[1], d[2], d[3]), reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p.aux_out) + (size_t)m * p.ldaux + n0));
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
     } else if constexpr (EPI == EPI_SIGMOID_F32) {
 #pragma unroll
@@ -122,9 +139,10 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
             make_float4(rr.res.x + v[0] * cc.colscale.x * s, rr.res.y + v[1] * cc.colscale.y * s, rr.res.z + v[2] * cc.colscale.z * s,
                         rr.res.w + v[3] * cc.colscale.w * s);
     } else if constexpr (EPI == EPI_DGELU) {
-        const float2 h01 = unpack_bf16x2(rr.aux.x), h23 = unpack_bf16x2(rr.aux.y);
+        float hd[4];
+        gelu8_unpack4(rr.aux.x, hd);
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) =
-            make_uint2(pack_bf16x2(v[0] * h01.x, v[1] * h01.y), pack_bf16x2(v[2] * h23.x, v[3] * h23.y));
+            make_uint2(pack_bf16x2(v[0] * hd[0], v[1] * hd[1]), pack_bf16x2(v[2] * hd[2], v[3] * hd[3]));
     }
 }
 
@@ -148,9 +166,9 @@ __device__ __forceinline__ EpiRow8 epi_load_row8(const GemmParams& p, int m, int
     r.aux = make_uint4(0, 0, 0, 0);
     if constexpr (EPI == EPI_DGELU) {
         if (ok) {                                 // read once, 10 ms after it was written: streaming load
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n0));
-            r.aux = make_uint4(t.x, t.y, t.z, t.w);
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.aux_in) + (size_t)m * p.ldaux + n0));
+            r.aux = make_uint4(t.x, t.y, 0, 0);
         }
     }
     return r;
@@ -168,13 +186,16 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, int m, int n0, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) gelu_erf_both2(ppf_float2{v[2 * i], v[2 * i + 1]}, g[i], d[i]);
         // gelu' is not read again before the backward pass: streaming (non-temporal) store, keeps L2 / MALL for the operands
-        const u32x4 dv = {pack_bf16x2(d[0].x, d[0].y), pack_bf16x2(d[1].x, d[1].y), pack_bf16x2(d[2].x, d[2].y), pack_bf16x2(d[3].x, d[3].y)};
-        __builtin_nontemporal_store(dv, reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n0));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 dv = {gelu8_pack4(d[0].x, d[0].y, d[1].x, d[1].y), gelu8_pack4(d[2].x, d[2].y, d[3].x, d[3].y)};
+        __builtin_nontemporal_store(dv, reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.aux_out) + (size_t)m * p.ldaux + n0));
         *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(g[0].x, g[0].y), pack_bf16x2(g[1].x, g[1].y), pack_bf16x2(g[2].x, g[2].y), pack_bf16x2(g[3].x, g[3].y));
     } else if constexpr (EPI == EPI_DGELU) {
-        const float2 h0 = unpack_bf16x2(rr.aux.x), h1 = unpack_bf16x2(rr.aux.y), h2 = unpack_bf16x2(rr.aux.z), h3 = unpack_bf16x2(rr.aux.w);
-        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0] * h0.x, v[1] * h0.y), pack_bf16x2(v[2] * h1.x, v[3] * h1.y),
-                                                    pack_bf16x2(v[4] * h2.x, v[5] * h2.y), pack_bf16x2(v[6] * h3.x, v[7] * h3.y));
+        float ha[4], hb[4];
+        gelu8_unpack4(rr.aux.x, ha);
+        gelu8_unpack4(rr.aux.y, hb);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0] * ha[0], v[1] * ha[1]), pack_bf16x2(v[2] * ha[2], v[3] * ha[3]),
+                                                    pack_bf16x2(v[4] * hb[0], v[5] * hb[1]), pack_bf16x2(v[6] * hb[2], v[7] * hb[3]));
     }
 }
 

@@ -5,7 +5,7 @@ import torch
 from protopformer_amd import ops
 M, D = 256 * 197, 384
 x = (torch.randn(M, D, device="cuda") * 0.5).bfloat16(); wq = (torch.randn(3 * D, D, device="cuda") * 0.5).bfloat16(); w1 = (torch.randn(4 * D, D, device="cuda") * 0.5).bfloat16()
-bias = torch.randn(4 * D, device="cuda"); h = torch.empty(M, 4 * D, dtype=torch.bfloat16, device="cuda")
+bias = torch.randn(4 * D, device="cuda"); h = torch.empty(M, 4 * D, dtype=torch.uint8, device="cuda")
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()

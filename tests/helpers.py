@@ -98,3 +98,15 @@ def report(name, **values):
             f.write(json.dumps({"test": name, **{k: (float(v) if v is not None else None) for k, v in values.items()}}) + "\n")
     except OSError:
         pass
+
+
+# gelu'(x) as the fc1 epilogue saves it for backward: 8-bit linear codes (csrc/gemm_common.h gelu8_*)
+GELU8_LO, GELU8_STEP = -0.13, 1.26 / 255.0
+
+
+def gelu8_decode(q):
+    return q.float() * GELU8_STEP + GELU8_LO
+
+
+def gelu8_encode(d):
+    return torch.clamp(torch.floor((d.float() - GELU8_LO) / GELU8_STEP + 0.5), 0, 255).to(torch.uint8)
