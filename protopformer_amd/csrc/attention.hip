@@ -12,8 +12,7 @@
 //   attn_fwd      O = softmax_policy(Q K^T * scale) V, saves row max and 1/(sum+eps) per (b,h,q)
 //   attn_headmean mean over heads of the probabilities -> (B, N, NP) fp32 (rollout input), recomputed from
 //                 the saved statistics (no B*H*N*N tensor ever exists)
-//   attn_bwd_dq   dQ (+ delta = rowsum(dO*O)),  one wave per 32-query tile
-//   attn_bwd_dkv  dK, dV,                        one wave per 32-key tile
+//   attn_bwd_stream / attn_bwd_onepass   dQ, dK, dV in one launch, every (query tile, key tile) pair visited once
 #include "ppf_common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -467,197 +466,6 @@ __global__ __launch_bounds__(256, 2) void attn_headmean_kernel(const AttnParams 
     }
 }
 
-// ------------------------------------------------------------------------------------------ backward: dQ
-template <int HD, int NT>
-__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dq_kernel(const AttnParams p) {
-    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + NT * 32 * 4];
-    unsigned char* tK = lds;
-    unsigned char* tV = lds + NT * 32 * 128;
-    float* pol = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);
-    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
-    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
-    const int q = q0 + (lane & 31), qc = min(q, N - 1);
-    const size_t si = ((size_t)b * p.H + h) * N + qc;
-    bf16x8 qf[KS], dof[KS], ovf[KS];
-    float mx, zi;
-    {
-        Stage<HD, NT * 32, NTHR> sk, sv;           // every global load of the prologue in flight before the first LDS write
-        sk.template load<true>(base + p.D, p.ld, 0, N, tid);
-        sv.template load<false>(base + 2 * p.D, p.ld, 0, N, tid);
-        const bf16_t* dorow = p.dout + ((size_t)b * N + qc) * p.D + h * HD;
-        const bf16_t* orow = p.out + ((size_t)b * N + qc) * p.D + h * HD;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * p.ld + ks * 16 + hh * 8);
-            dof[ks] = *reinterpret_cast<const bf16x8*>(dorow + ks * 16 + hh * 8);
-            ovf[ks] = *reinterpret_cast<const bf16x8*>(orow + ks * 16 + hh * 8);
-        }
-        mx = p.rowmax[si]; zi = p.zinv[si];
-        for (int i = tid; i < NT * 32; i += NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
-        sk.store(tK, tid);
-        sv.store(tV, tid);
-    }
-    __syncthreads();
-    if (q0 >= N) return;
-    const int qself = p.self_keep ? q : -1;
-    float dl = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ovf[ks][e];
-    dl += __shfl_xor(dl, 32, 64);
-    if (hh == 0 && q < N) p.delta[si] = dl;
-    f32x16 dq[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
-        f32x16 s, g;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, t * 32, ks, lane), qf[ks], s, 0, 0, 0);
-            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tV, t * 32, ks, lane), dof[ks], g, 0, 0, 0);
-        }
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            const int key0 = t * 32 + 8 * gg + 4 * hh;
-            const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
-            const float keep[4] = {kp.x, kp.y, kp.z, kp.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float k = (key0 + i == qself) ? 1.0f : keep[i];
-                const float pt = __expf(s[4 * gg + i] * p.scale - mx) * k * zi;   // padded keys: keep = 0
-                s[4 * gg + i] = pt * (g[4 * gg + i] - dl);           // dS (before the scale factor)
-            }
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const bf16x8 dsf = pack8(s, 8 * st);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, t * 32 + 16 * st, dt * 32, lane), dsf, dq[dt], 0, 0, 0);
-        }
-    }
-    if (q < N) {
-        bf16_t* row = p.dqkv + ((size_t)b * N + q) * p.ld + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + 8 * g + 4 * hh;
-                if (d < HD)
-                    *reinterpret_cast<uint2*>(row + d) = make_uint2(pack_bf16x2(dq[dt][4 * g] * p.scale, dq[dt][4 * g + 1] * p.scale),
-                                                                    pack_bf16x2(dq[dt][4 * g + 2] * p.scale, dq[dt][4 * g + 3] * p.scale));
-            }
-    }
-}
-
-// --------------------------------------------------------------------------------------- backward: dK, dV
-template <int HD, int NT>
-__global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
-    constexpr int NW = Geo<NT>::NW, NTHR = Geo<NT>::NTHR;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NT * 32 * 128 + 3 * NT * 32 * 4];
-    unsigned char* tQ = lds;
-    unsigned char* tO = lds + NT * 32 * 128;
-    float* st_m = reinterpret_cast<float*>(lds + 2 * NT * 32 * 128);
-    float* st_z = st_m + NT * 32;
-    float* st_d = st_z + NT * 32;
-    constexpr int DT = (HD + 31) / 32, KS = HD / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, N = p.N;
-    const bf16_t* base = p.qkv + (size_t)b * N * p.ld + h * HD;
-    const int k0 = (blockIdx.x * NW + wave) * 32;
-    const int key = k0 + (lane & 31), kc = min(key, N - 1);
-    bf16x8 kf[KS], vf[KS];
-    float keep_key;
-    {
-        Stage<HD, NT * 32, NTHR> sq, so;           // every global load of the prologue in flight before the first LDS write
-        sq.template load<false>(base, p.ld, 0, N, tid);
-        so.template load<false>(p.dout + (size_t)b * N * p.D + h * HD, p.D, 0, N, tid);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *reinterpret_cast<const bf16x8*>(base + p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
-            vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * p.D + (size_t)kc * p.ld + ks * 16 + hh * 8);
-        }
-        keep_key = key < N ? (p.policy ? p.policy[(size_t)b * N + kc] : 1.0f) : 0.f;
-        for (int i = tid; i < NT * 32; i += NTHR) {
-            const size_t si = ((size_t)b * p.H + h) * N + i;
-            st_m[i] = i < N ? p.rowmax[si] : 0.f;
-            st_z[i] = i < N ? p.zinv[si] : 0.f;       // zero => padded queries contribute nothing
-            st_d[i] = i < N ? p.delta[si] : 0.f;
-        }
-        sq.store(tQ, tid);
-        so.store(tO, tid);
-    }
-    __syncthreads();
-    if (k0 >= N) return;
-    const int kself = p.self_keep ? key : -1;
-    const float c = p.eps_c;
-    f32x16 dk[DT], dv[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-#pragma unroll 1
-    for (int t = 0; t < NT; ++t) {
-        f32x16 s, g;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; g[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tQ, t * 32, ks, lane), kf[ks], s, 0, 0, 0);   // [q][key]
-            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tO, t * 32, ks, lane), vf[ks], g, 0, 0, 0);   // dO.V^T
-        }
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            const int qq0 = t * 32 + 8 * gg + 4 * hh;
-            const float4 m4 = *reinterpret_cast<const float4*>(st_m + qq0), z4 = *reinterpret_cast<const float4*>(st_z + qq0),
-                         d4 = *reinterpret_cast<const float4*>(st_d + qq0);
-            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float k = (qq0 + i == kself) ? 1.0f : keep_key;
-                const float pt = __expf(s[4 * gg + i] * p.scale - mm[i]) * k * zz[i];
-                s[4 * gg + i] = pt * (g[4 * gg + i] - dd[i]);          // dS[q][key]
-                g[4 * gg + i] = pt + c * zz[i];                         // out[q][key]
-            }
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const bf16x8 dsf = pack8(s, 8 * st), pf = pack8(g, 8 * st);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, t * 32 + 16 * st, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tO, t * 32 + 16 * st, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-            }
-        }
-    }
-    if (key < N) {
-        bf16_t* krow = p.dqkv + ((size_t)b * N + key) * p.ld + p.D + h * HD;
-        bf16_t* vrow = krow + p.D;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + 8 * g + 4 * hh;
-                if (d < HD) {
-                    *reinterpret_cast<uint2*>(krow + d) = make_uint2(pack_bf16x2(dk[dt][4 * g] * p.scale, dk[dt][4 * g + 1] * p.scale),
-                                                                     pack_bf16x2(dk[dt][4 * g + 2] * p.scale, dk[dt][4 * g + 3] * p.scale));
-                    *reinterpret_cast<uint2*>(vrow + d) = make_uint2(pack_bf16x2(dv[dt][4 * g], dv[dt][4 * g + 1]), pack_bf16x2(dv[dt][4 * g + 2], dv[dt][4 * g + 3]));
-                }
-            }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------ backward, one pass
 // Every (query tile, key tile) pair is visited ONCE: wave w owns key tile w (its K / V fragments stay in registers, dK / dV
 // accumulate in registers) and walks the query tiles in the rotated order t = (w + i) mod NT, so that in step i the NT waves work on
@@ -885,11 +693,9 @@ __global__ __launch_bounds__(Geo<NT>::NTHR, 2) void attn_bwd_onepass_kernel(cons
 //     chunk swizzle on the SOURCE address); K / V / O rows of the wave's own 32 keys / queries go straight to registers; K^T fragments
 //     come from a transposed read of the wave's own 4 KiB scratch tile.  No K / V / O images, no staging registers.  Results leave
 //     through the wave's OWN scratch tile as 16-byte row-contiguous stores, without any workgroup barrier.
-//   * A pair is split into P1 (S, dP products; softmax + dS arithmetic; dS^T to the scratch tile) and P2 (dK, dV products; dQ product +
-//     read-modify-write).  Waves 0-3 and waves 4-6 -- the two waves that share a SIMD are one of each -- run HALF A STEP APART: while
-//     one does the VALU-heavy P1 its SIMD partner does the MFMA / LDS-heavy P2.  2 NT + 1 half-steps per item, one barrier each; the
-//     tiles under read-modify-write in a half-step belong to one group only and are distinct (rotation), and the order in which the key
-//     tiles reach a query tile is fixed by the schedule: bit-identical from run to run, no atomics.
+//   * NT waves (no idle eighth wave), 1 + NT barriers per item.  (Running the two waves of a SIMD half a step apart -- one in the VALU-heavy
+//     first half of a pair, its partner in the MFMA / LDS-heavy second half -- was built and measured: no gain, the waves are latency-bound,
+//     not issue-bound: WAIT_ANY 50 %, MFMA 16 %, LDS 32 %, VALU 13 % busy; profiles/r4_attn_bwd.txt.)
 //   * 1/sum of the softmax is folded into the exponent (row statistic m' = m log2(e) - log2(1/sum)); the key-keep factor is applied only
 //     where a key can be masked (policy given, or the tile holding the padded keys).
 // Padded queries (rows >= N of the images repeat row N - 1, finite) are neutralised by their statistics: m' = +3e38 -> exp2 -> 0, eps
@@ -906,7 +712,6 @@ __global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnP
     constexpr int DT = (HD + 31) / 32, KS = HD / 16;
     constexpr int DQT = DT * 4 * 64 * 4;                        // floats of one query tile's dQ accumulator: [dt][g][lane][4]
     constexpr int PPW = 8;                                      // 1 KiB pieces per wave: 4 of the Q image, 4 of the dO image (4 NT each)
-    constexpr int G0 = NT;                                     // waves [0, G0) lead, waves [G0, NT) run half a step behind (measured: no gain, off)
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -922,7 +727,6 @@ __global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnP
     const int N = p.N, H = p.H;
     const int r0 = wave * 32;                      // this wave's key tile (and the query tile whose statistics / dQ rows it handles)
     const bool active = r0 < N;
-    const bool lag = wave >= G0;
     const bool masked = p.policy != nullptr || r0 + 32 > N;      // wave-uniform: some key of this tile may carry keep = 0
     const int row = r0 + l31, rc = min(row, N - 1);
     unsigned char* scr = scr_all + wave * 4096;
@@ -1100,18 +904,11 @@ __global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnP
                 for (int gq = 0; gq < 4; ++gq)
                     *reinterpret_cast<float4*>(qa + (dt * 4 + gq) * 256) = make_float4(dq[dt][4 * gq], dq[dt][4 * gq + 1], dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
         };
-        // Both groups run the same instruction stream "P1(i); barrier; P2(i); barrier"; the lagging group enters it one barrier later and
-        // the leading group waits one barrier longer at the end, so between two barriers one group is in P1 and the other in P2.
-        // (s_barrier counts arrivals of the workgroup's waves: the call sites need not be the same, the COUNT per wave is: 2 NT + 1.)
-        if (lag) __syncthreads();
 #pragma unroll 1
         for (int i = 0; i < NT; ++i) {
-            if (active && !(p.ko & 1)) p1(i);
-            if constexpr (G0 < NT) __syncthreads();
-            if (active && !(p.ko & 1)) p2(i);
-            __syncthreads();
+            if (active && !(p.ko & 1)) { p1(i); p2(i); }
+            __syncthreads();                           // the next step's owner of each query tile sees this step's sums
         }
-        if (!lag) __syncthreads();
         // ---- every wave is past the last pair: the images are dead.  The next item's loads go out first, this item's results after them.
         const int nxt = item + gridDim.x;
         if (nxt < nitems && !(p.ko & 4)) { issue_images(nxt); load_rows(nxt); }
@@ -1254,13 +1051,12 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
-    static const int fused = getenv("PPF_ATTN_BWD_FUSED") ? atoi(getenv("PPF_ATTN_BWD_FUSED")) : 2;
+    static const int mode = getenv("PPF_ATTN_BWD_STREAM") ? atoi(getenv("PPF_ATTN_BWD_STREAM")) : 1;      // 0: the non-persistent one-pass kernel (A/B)
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
-        dim3 grid((N + G::NW * 32 - 1) / (G::NW * 32), H, B);
         constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
         if constexpr (HDv == 64) {
-            if (fused >= 2) {   // the streaming form of the one-pass kernel (default)
+            if (mode) {         // the streaming form of the one-pass kernel (default)
                 constexpr int lds_bytes = StreamLds<HDv, NTv>::BYTES;
                 auto kern = attn_bwd_stream_kernel<HDv, NTv>;
                 static bool attr_set = false;
@@ -1285,7 +1081,7 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
                 return 0;
             }
         }
-        if (fused) {            // one pass over the (query tile, key tile) pairs (PPF_ATTN_BWD_FUSED=0: the two-kernel form dq + dkv)
+        {                       // other head widths: the non-persistent one-pass kernel
             constexpr int lds_bytes = OnePassLds<HDv, NTv>::BYTES;
             auto kern = attn_bwd_onepass_kernel<HDv, NTv>;
             static bool attr_set = false;                  // one flag per instantiation (the lambda is instantiated per (hd, nt))
@@ -1298,11 +1094,6 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
             PPF_LAUNCH_CHECK();
             return 0;
         }
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(G::NTHR), 0, stream, p);
-        PPF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<decltype(hd)::value, decltype(nt)::value>), grid, dim3(G::NTHR), 0, stream, p);
-        PPF_LAUNCH_CHECK();
-        return 0;
     });
 }
 

@@ -41,31 +41,10 @@ __device__ __forceinline__ int lds_off_mode1(int kc, int col) {
     return kc * (ROWS * 2) + ((((col >> 5) ^ (kc & 3))) << 6) + ((col & 31) << 1);
 }
 
-// 16-byte global load the compiler does not track (inline asm): with ordinary loads hipcc re-derives the outstanding-load count
-// at the loop header of the register pipeline and waits vmcnt(2) before every refill, draining the pipeline each K step.  The
-// consumer waits by hand (gemm_vmwait<N>) right before the registers are stored to LDS.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));       // a native 128-bit register tuple (inline-asm operand)
-__device__ __forceinline__ u32x4 gload_async(const void* ptr) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
-// The wait names the registers it guards as in/out operands: everything that reads them (the zero-fill select, ds_write) is then
-// data-dependent on the wait and cannot be scheduled above it.
-template <int N>
-__device__ __forceinline__ void gemm_vmwait(u32x4 (&a)[4], u32x4 (&b)[4]) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 : "n"(N)
-                 : "memory");
-}
-template <int N>
-__device__ __forceinline__ void gemm_vmwait_all() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));       // a native 128-bit register tuple
 
 // Operand tile of ROWS rows (m or n) x 64 contraction values, staged global -> registers -> LDS by 256 threads.
-template <bool T, int ROWS, bool ASYNC = false>
+template <bool T, int ROWS>
 struct TileIO {
     static constexpr int NLD = ROWS / 32;            // 16-byte loads per thread
     // Branch-free: every load is issued unconditionally from a clamped (always valid) address and the "outside the matrix"
@@ -82,7 +61,7 @@ struct TileIO {
             for (int i = 0; i < NLD; ++i) {
                 const int r = row0 + rb + 32 * i;
                 const bf16_t* src = X + (size_t)min(r, R - 1) * ld + kk;
-                if constexpr (ASYNC) reg[i] = gload_async(src); else reg[i] = *reinterpret_cast<const u32x4*>(src);
+                reg[i] = *reinterpret_cast<const u32x4*>(src);
                 mask |= (kok && r < R) ? (1u << i) : 0u;
             }
         } else {
@@ -95,7 +74,7 @@ struct TileIO {
             for (int i = 0; i < NLD; ++i) {
                 const int kc = k0 + kb + (256 / CPR) * i;
                 const bf16_t* src = X + (size_t)min(kc, kend - 1) * ld + cc;
-                if constexpr (ASYNC) reg[i] = gload_async(src); else reg[i] = *reinterpret_cast<const u32x4*>(src);
+                reg[i] = *reinterpret_cast<const u32x4*>(src);
                 mask |= (cok && kc < kend) ? (1u << i) : 0u;
             }
         }
@@ -193,19 +172,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, const float* 
 
 // MT = 32-row MFMA tiles per wave along m: MT = 2 -> 128x128 workgroup tile (3 workgroups/CU), MT = 4 -> 256x128 (wave tile
 // 128x64, 2 workgroups/CU): fewer LDS bytes and barriers per flop for the tall activation GEMMs (M = B*N tokens).
-// PD = K tiles in flight per workgroup (register stages): 1 = the next tile is prefetched while the current one is multiplied (three
-// workgroups per CU); 3 = three tiles ahead, 96 staging registers, two workgroups per CU -- for operands streamed from HBM over a
-// long contraction (weight gradients: 50 432 tokens) one tile ahead leaves every K step exposed to a full memory round trip.
-template <bool TA, bool TB, int EPI, bool COLSUM, int MT, int PD>
-__global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_kernel(const GemmParams p_) {
+// The next K tile is prefetched into registers while the current one is multiplied (three workgroups per CU).  (A three-deep register
+// pipeline with hand-counted waits was measured equal stand-alone and 1.8 % slower in the step -- the kernel is not latency-bound,
+// profiles/r2_wgrad_pmc.txt -- and removed in round 4.)
+template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
+__global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const GemmParams p_) {
+    constexpr int PD = 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TBM = 64 * MT;                    // workgroup tile rows
     constexpr int A_BYTES = TBM * BK * 2;
-    constexpr bool ASYNC = PD > 1;                  // the deeper register pipeline counts its loads by hand
-    using IOA = TileIO<TA, TBM, ASYNC>;
-    using IOB = TileIO<TB, BN, ASYNC>;
-    constexpr int LPS = IOA::NLD + IOB::NLD;        // loads per stage and thread
-    static_assert(!ASYNC || (IOA::NLD == 4 && IOB::NLD == 4), "the hand-counted pipeline is written for 128x128 tiles");
+    using IOA = TileIO<TA, TBM>;
+    using IOB = TileIO<TB, BN>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * (32 * MT), wn = (wave >> 1) * 64;
 
@@ -260,7 +237,6 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
         ma[st] = IOA::gload(ra[st], p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
         mb[st] = IOB::gload(rb[st], p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
     }
-    if constexpr (ASYNC) gemm_vmwait<(PD - 1) * LPS>(ra[0], rb[0]);
     IOA::sstore(ra[0], ma[0], tA, tid);
     IOB::sstore(rb[0], mb[0], tB, tid);
     __syncthreads();
@@ -301,7 +277,6 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
                 }
             }
             __syncthreads();                                 // single LDS operand buffer: everyone finished reading it
-            if constexpr (ASYNC) gemm_vmwait<(PD - 1) * LPS>(ra[(u + 1) % PD], rb[(u + 1) % PD]);      // the oldest stage has landed; PD-1 stay in flight
             if (kt + 1 < nk) {
                 IOA::sstore(ra[(u + 1) % PD], ma[(u + 1) % PD], tA, tid);
                 IOB::sstore(rb[(u + 1) % PD], mb[(u + 1) % PD], tB, tid);
@@ -310,7 +285,6 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
         }
     }
 
-    if constexpr (ASYNC) gemm_vmwait_all<0>();       // refills past the end are still in flight: retire them before the epilogue's loads
     // epilogue.  After the MFMAs a lane holds, for each (ni, mi): row m = wm+32*mi+(lane&31) and, for g = 0..3, the four
     // consecutive columns n = wn+32*ni+8*g+4*(lane>>5).. (acc regs 4g..4g+3): row-strided 8/16-byte pieces.  Each wave
     // therefore transposes its accumulators through a private LDS strip (32 rows x 64 fp32 at a time) so that 16
@@ -334,66 +308,8 @@ __global__ __launch_bounds__(NTHREADS, (MT == 2 && PD == 1) ? 3 : 2) void gemm_k
             if (do_colsum && h == 0 && m < p.M) {
                 if constexpr (EPI == EPI_PARTIAL) {
                     float* dst = p.ws + p.zslice * ((size_t)p.M * p.N + (size_t)p.cs_parts * p.M) + (size_t)p.M * p.N + m;
-                    if (p.counters) __hip_atomic_store(dst, accs[mi][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through, as the tiles
-                    else *dst = accs[mi][0];
+                    *dst = accs[mi][0];
                 } else unsafeAtomicAdd(p.colsum + m, accs[mi][0]);
-            }
-        }
-    }
-    if constexpr (EPI == EPI_PARTIAL && MT == 2) {
-        if (p.counters != nullptr) {
-            // Split-K fix-up by the LAST-ARRIVING slice of this output tile (write-through partial stores, drained by every wave, then a
-            // relaxed agent-scope ticket; the reducer acquires once -- cdna_hip_programming.md G16 R1): it adds the nsplit partial tiles in slice order -- the same order whoever arrives last, so
-            // the result stays bit-reproducible -- and accumulates them into C.  No separate reduce launch; the partials are read back
-            // out of L2 / the memory-side cache shortly after they were written.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its partial stores have left the CU
-            __syncthreads();
-            unsigned* flag = reinterpret_cast<unsigned*>(smem);               // (the operand tiles / epilogue strips are dead)
-            if (tid == 0) *flag = __hip_atomic_fetch_add(p.counters + vid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const bool last = *flag == (unsigned)(nsplit - 1);
-            if (last) {                                                       // uniform
-                if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); p.counters[vid] = 0u; }       // zero again for the next call
-                __syncthreads();
-                const size_t mn = (size_t)p.M * p.N, slice = mn + (p.colsum ? (size_t)p.cs_parts * p.M : 0);
-                float* C = reinterpret_cast<float*>(p.C);
-                const int c4 = (tid & 31) * 4, r0 = tid >> 5;
-                // 16 independent row pieces per thread and slice: the loads of one slice are in flight together (a per-piece loop over
-                // the slices is one dependent L2 / memory round trip per load: measured 150 us per tile instead of ~10)
-                float4 a[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int n = n0 + c4;
-                const bool nok = n < p.N;
-                for (int z = 0; z < nsplit; ++z) {
-                    const float* src = p.ws + (size_t)z * slice + n;
-                    float4 v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int m = m0 + r0 + 8 * i;
-                        v[i] = (nok && m < p.M) ? *reinterpret_cast<const float4*>(src + (size_t)m * p.N) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { a[i].x += v[i].x; a[i].y += v[i].y; a[i].z += v[i].z; a[i].w += v[i].w; }
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int m = m0 + r0 + 8 * i;
-                    if (nok && m < p.M) {
-                        float4* dst = reinterpret_cast<float4*>(C + (size_t)m * p.ldc + n);
-                        const float4 c = *dst;
-                        *dst = make_float4(c.x + a[i].x, c.y + a[i].y, c.z + a[i].z, c.w + a[i].w);
-                    }
-                }
-                if (COLSUM && p.colsum != nullptr && n0 == 0 && tid < TBM) {
-                    const int m = m0 + tid;
-                    if (m < p.M) {
-                        float a = 0.f;
-                        for (int z = 0; z < nsplit; ++z)
-                            for (int q = 0; q < p.cs_parts; ++q) a += p.ws[(size_t)z * slice + mn + (size_t)q * p.M + m];
-                        p.colsum[m] += a;
-                    }
-                }
             }
         }
     }
@@ -519,11 +435,11 @@ bool g4_eligible(const GemmParams& p) {
            (long long)p.N * p.ldb < (1ll << 30) && (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) >= 512;
 }
 
-template <bool TA, bool TB, int EPI, bool COLSUM, int MT, int PD = 1>
+template <bool TA, bool TB, int EPI, bool COLSUM, int MT>
 int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch) {
     constexpr int TBM = 64 * MT;
     const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + BN - 1) / BN);
-    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, MT, PD>;
+    auto kern = gemm_kernel<TA, TB, EPI, COLSUM, MT>;
     constexpr int opnd = TBM * BK * 2 + TILE_BYTES;
     constexpr int lds = opnd > STAGE_BYTES ? opnd : STAGE_BYTES;
     static bool attr_set = false;
@@ -551,12 +467,6 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) 
     // img/s against 15.6k -- profiles/r4_wgrad_tiles.txt)
     const bool tall = forced == 4;
     if (tall) return launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch);
-    // PPF_GEMM_PD=3: three K tiles in flight for the long-contraction weight gradients (measured equal to one tile ahead: the kernel is
-    // not latency-bound -- SQ_WAIT_ANY 22 %, issue stalls 47 % -- profiles/r2_wgrad_pmc.txt), default 1
-    static const int pd = getenv("PPF_GEMM_PD") ? atoi(getenv("PPF_GEMM_PD")) : 1;
-    if constexpr (TA && TB && (EPI == EPI_PARTIAL || EPI == EPI_ATOMIC)) {
-        if (pd == 3 && nbatch == 1) return launch_impl<TA, TB, EPI, COLSUM, 2, 3>(p, splitk, stream, nbatch);
-    }
     return launch_impl<TA, TB, EPI, COLSUM, 2>(p, splitk, stream, nbatch);
 }
 
@@ -630,9 +540,8 @@ struct Probe {
 };
 Probe g_probe;
 
-// The first PPF_GEMM_COUNTER_BYTES of a split-K workspace are the per-tile arrival counters of the in-kernel fix-up: the CALLER hands
-// over a workspace that was zero-filled when it was allocated and is used by ppf_gemm_bf16 calls of ONE stream only; every call
-// leaves the counters zero again.
+// The first PPF_GEMM_COUNTER_BYTES of a split-K workspace are reserved (they held the arrival counters of the in-kernel reduce of round
+// 3; the layout of the ABI is kept): the CALLER hands over a workspace used by ppf_gemm_bf16 calls of ONE stream only.
 constexpr size_t PPF_GEMM_COUNTER_BYTES = 16384;
 
 int pick_splitk(int M, int N, int K) {
@@ -657,10 +566,7 @@ extern "C" {
 
 // Bytes of split-K workspace ppf_gemm_bf16 needs for an accumulating (epi = 6) problem of this shape.
 size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
-    const size_t a = PPF_GEMM_COUNTER_BYTES + (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
-    const size_t b = PPF_GEMM_COUNTER_BYTES + (size_t)nt256_wgrad_slices(M, N, K, 8, 8) * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);       // 256x256 paths
-    const size_t c = PPF_GEMM_COUNTER_BYTES + (size_t)tt_deep_slices(M, N, K, 8, 8) * ((size_t)M * N + M) * sizeof(float);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    return PPF_GEMM_COUNTER_BYTES + (size_t)pick_splitk(M, N, K) * ((size_t)M * N + M) * sizeof(float);
 }
 
 // Generic entry. trans_a / trans_b select the storage modes described at the top of this file.
@@ -686,7 +592,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.res = res; p.ldres = ldres; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.ldaux = ldaux; p.colsum = colsum; p.alpha = alpha; p.ws = nullptr;
-    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0; p.cs_parts = 1; p.nsplit = 1; p.counters = nullptr;
+    p.batch_inner = 1; p.sa_o = p.sa_i = p.sb_o = p.sb_i = p.sc_o = p.sc_i = 0; p.kpad = 0; p.cs_parts = 1; p.nsplit = 1;
     if (epi == EPI_RESID) PPF_CHECK_ARG(res != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=4 needs a residual");
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
@@ -720,37 +626,25 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     } else {
         switch (epi) {
             case EPI_ATOMIC: {
-                // three kernels can take a weight gradient: the deep-ring 256x256 kernel (default where eligible), the two-K-tile
-                // 256x256 kernel (opt-in) and the 128x128 kernel
-                const int nsd = workspace ? tt_deep_slices(M, N, K, lda, ldb) : 0;
-                const bool deep = nsd > 0 && workspace_bytes >= PPF_GEMM_COUNTER_BYTES + (size_t)nsd * ((size_t)M * N + M) * sizeof(float);
-                const int ns256 = (!deep && workspace) ? nt256_wgrad_slices(M, N, K, lda, ldb) : 0;
-                const bool big = ns256 > 0 && workspace_bytes >= PPF_GEMM_COUNTER_BYTES + (size_t)ns256 * ((size_t)M * N + 4 * (size_t)M) * sizeof(float);
-                const int ns = deep ? nsd : big ? ns256 : pick_splitk(M, N, K);
+                // split over the contraction: with a workspace the K slices leave fp32 partial tiles that splitk_reduce_kernel adds to C in
+                // slice order (the 28 MB of slabs are recycled by every weight gradient and stay in the L2 / memory-side cache:
+                // profiles/r4_reduce_batch.txt); without one: fp32 atomics.  (The 256x256 weight-gradient kernels of rounds 1-3 and the
+                // in-kernel last-arriver reduce were measured slower IN THE STEP once more in round 4 and deleted: profiles/r4_wgrad_tiles.txt.)
+                const int ns = pick_splitk(M, N, K);
                 const size_t need = PPF_GEMM_COUNTER_BYTES + (size_t)ns * ((size_t)M * N + M) * sizeof(float);
-                if (!deep && !big && (workspace == nullptr || workspace_bytes < need || ns == 1)) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
+                if (workspace == nullptr || workspace_bytes < need || ns == 1) return launch<true, true, EPI_ATOMIC, true>(p, ns, stream);
                 p.ws = (float*)((unsigned char*)workspace + PPF_GEMM_COUNTER_BYTES);
-                p.cs_parts = big ? 4 : 1;
+                p.cs_parts = 1;
                 p.nsplit = ns;
-                // PPF_SPLITK_FUSED=1: the in-kernel fix-up by the last-arriving slice instead of the separate ordered reduce launch.
-                // Measured (round 3, same box, profiles/r3_splitk_fused.txt): correct and bit-reproducible, but SLOWER -- 14 669 vs 15 842
-                // img/s (deit_small), 15.7k vs 22.7k (deit_tiny), 5.5k vs 6.4k (cait_xxs24): a tile's 12-43 partial slabs of 64 KiB are
-                // then read by ONE workgroup (0.8-2.8 MB at ~65 GB/s per workgroup) while the reduce kernel spreads them over the chip;
-                // the guide's rule (in-launch combine only for a few tens of KB per tile) holds.  Opt-in, default off.
-                static const int fused_mode = getenv("PPF_SPLITK_FUSED") ? atoi(getenv("PPF_SPLITK_FUSED")) : 0;
-                const int tiles128 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-                const bool fused = fused_mode && !deep && !big && (size_t)tiles128 * sizeof(unsigned) <= PPF_GEMM_COUNTER_BYTES;
-                p.counters = fused ? (unsigned*)workspace : nullptr;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (g_probe.on) { auto ev = g_probe.acquire(); e0 = ev.first; e1 = ev.second; (void)hipEventRecord(e0, stream); }
-                int rc = deep ? launch_tt_deep(p, stream) : big ? launch_nt256_wgrad(p, stream) : launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
+                int rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
                 if (g_probe.on) {
                     (void)hipEventRecord(e1, stream);
                     g_probe.flops += 2.0 * M * N * (double)K;
                     g_probe.bytes += 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N;
                 }
-                if (fused) return 0;                                  // the last-arriving slices already accumulated into C / colsum
                 const size_t work = (size_t)M * N / 4 + (colsum ? M : 0);
                 const int grid = (int)((work + 63) / 64);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns, p.cs_parts);
@@ -815,7 +709,6 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.rowscale = nullptr; p.rows_per_group = 1; p.colscale = nullptr; p.aux_in = nullptr;
     p.aux_out = nullptr; p.ldaux = 0; p.colsum = nullptr; p.ws = nullptr; p.alpha = alpha;
-    p.counters = nullptr;
     p.batch_inner = batch_inner; p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i; p.kpad = kpad;
     const int nb = batch_outer * batch_inner;
     const int key = (trans_a ? 4 : 0) | (trans_b ? 2 : 0) | (out_f32 ? 1 : 0);

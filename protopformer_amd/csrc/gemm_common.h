@@ -26,10 +26,8 @@ struct GemmParams {
     long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
     int zslice;              // (device side) this workgroup's K slice
     int nsplit;              // split-K slices; grid.x = tiles * nsplit, slice-major so that an XCD owns whole K slices
-    int cs_parts;            // EPI_PARTIAL: partial column sums per slice and row (1: gemm_bf16.hip, 4: gemm_nt256.hip)
+    int cs_parts;            // EPI_PARTIAL: partial column sums per slice and row (1)
     int kpad;                // 1: contraction-contiguous operands may read up to the next multiple of 8 beyond K (zero/finite padding)
-    unsigned* counters;      // EPI_PARTIAL: per-output-tile arrival counters (zero between calls): the LAST slice to arrive adds the tile's
-                             // partials up in slice order and accumulates them into C (no separate reduce launch); null: splitk_reduce_kernel
 };
 
 // gelu'(x) of the erf GELU lies in [-0.1290, 1.1290]: it is saved for the backward pass as an 8-bit linear code (round 4):
@@ -102,15 +100,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
     if constexpr (EPI == EPI_PARTIAL) {
         const size_t slice = (size_t)p.M * p.N + (p.colsum ? (size_t)p.cs_parts * p.M : 0);
         float* dst = p.ws + p.zslice * slice + (size_t)m * p.N + n0;
-        if (p.counters) {
-            // partial tiles that another workgroup adds up INSIDE this launch leave as write-through (sc1) stores: no release fence
-            // (= a write-back of every dirty line of the XCD's L2, which holds the other stream's output at that moment) is needed
-            // before the arrival ticket, only the counted drain of these stores (cdna_hip_programming.md G16 R1)
-            const f32x4 val = {v[0], v[1], v[2], v[3]};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
-        } else {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         return;
     }
     v[0] += cc.bias.x; v[1] += cc.bias.y; v[2] += cc.bias.z; v[3] += cc.bias.w;
@@ -202,9 +192,5 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, int m, int n0, c
 // 256x256x64 pipelined kernel for contraction-contiguous operands (gemm_nt256.hip)
 bool nt256_eligible(const GemmParams& p, int epi);
 int launch_nt256(const GemmParams& p, int epi, hipStream_t stream);
-int nt256_wgrad_slices(int M, int N, int K, int lda, int ldb);
-int launch_nt256_wgrad(const GemmParams& p, hipStream_t stream);
-int tt_deep_slices(int M, int N, int K, int lda, int ldb);
-int launch_tt_deep(const GemmParams& p, hipStream_t stream);
 
 }  // namespace ppfg

@@ -1,5 +1,5 @@
 """Weight-gradient GEMM (both operands contraction-strided, split-K + ordered reduce) vs an fp32 torch reference, at the train
-step's shapes; the 256x256 global_load_lds path (PPF_GEMM_NT256_WGRAD=1, default) and the 128x128 path (=0) must agree."""
+step's shapes, with bit-identical repeats."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -9,6 +9,9 @@ from oracle import ppf_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+# gradient-direction gates of the two backbone tests below: 3 x the deficit measured on MI355X (profiles/r4_tol_report.jsonl)
+GATE_MICRO_BACKBONE, GATE_REAL_BACKBONE = 0.9996, 0.9995          # measured 0.99988 / 0.99986
+
 
 class _P:
     pass
@@ -196,7 +199,8 @@ def test_micro_cait_against_reference_fixture():
             continue
         cos[name] = float(torch.dot(gflat, ref) / (gflat.norm() * ref.norm()).clamp_min(1e-30))
     report("micro_cait_grads", worst_cos=min(cos.values()))
-    bad = {k: v for k, v in cos.items() if v < 0.93}
+    # measured on MI355X: worst cosine 0.99953 (profiles/r4_tol_report.jsonl); gate = 3 x the measured deficit
+    bad = {k: v for k, v in cos.items() if v < 0.9986}
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
 
@@ -225,7 +229,8 @@ def test_micro_cait_backbone_grads_vs_oracle():
             continue
         rows[name] = (float((gm - gr).abs().max() / gr.abs().max()), float(torch.dot(gm, gr) / (gm.norm() * gr.norm()).clamp_min(1e-30)))
     assert len(rows) > 80
-    bad = {k: v for k, v in rows.items() if v[1] < 0.98}
+    report("micro_cait_backbone_grads", worst_cos=min(v[1] for v in rows.values()))
+    bad = {k: v for k, v in rows.items() if v[1] < GATE_MICRO_BACKBONE}
     assert not bad, bad
 
 
@@ -282,5 +287,6 @@ def test_real_shape_cait_xxs24_train_step_vs_oracle():
             continue
         cosines[name] = float(torch.dot(gm, gr) / (gm.norm() * gr.norm()).clamp_min(1e-30))
     assert len(cosines) > 300
-    bad = {k: v for k, v in cosines.items() if v < 0.97}
+    report("real_shape_cait_backbone_grads", worst_cos=min(cosines.values()))
+    bad = {k: v for k, v in cosines.items() if v < GATE_REAL_BACKBONE}
     assert not bad, bad
