@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libppf_hip.so")
+LIB_PATH = os.environ.get("PPF_LIB_PATH") or os.path.join(_HERE, "lib", "libppf_hip.so")      # PPF_LIB_PATH: an alternative build (same-box A/B of two builds)
 
 # signature spec per entry point: p = device/host pointer, i = int32, l = int64, L = uint64, f = float, z = size_t, s = hipStream_t
 SIGS = {

@@ -35,6 +35,27 @@ def _compile(src, obj):
     return src
 
 
+def build_variant(tag, defines, verbose=True):
+    """A second library lib/libppf_hip_<tag>.so compiled with extra -D switches (measurement builds for same-box A/Bs through PPF_LIB_PATH)."""
+    objdir = os.path.join(LIBDIR, "obj_" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(SRC, "*.hip")))
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    def one(a):
+        r = subprocess.run([HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-c", a[0], "-o", a[1]], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {a[0]}:\n{r.stderr}")
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(one, zip(srcs, objs)))
+    lib = os.path.join(LIBDIR, f"libppf_hip_{tag}.so")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    if verbose:
+        print("[ppf build] linked", lib, flush=True)
+    return lib
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(SRC, "*.hip")))
@@ -61,4 +82,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python -m protopformer_amd.build --variant TAG DEFINE [DEFINE ...]
+        build_variant(sys.argv[2], sys.argv[3:])
+    else:
+        build(force="--force" in sys.argv)
