@@ -61,9 +61,8 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                   int rows_per_group, const float* colscale, const void* aux_in, void* aux_out, int ldaux, float* colsum,
                   float alpha, void* workspace, size_t workspace_bytes, ppf_stream_t stream);
 /* split-K scratch an accumulating (epi 6) GEMM of this shape wants (deterministic ordered reduction instead of atomics).  Contract: the
- * workspace was ZERO-FILLED when it was allocated and is handed to ppf_gemm_bf16 calls of one stream only -- its first 16 KiB are the
- * per-tile arrival counters of the in-kernel fix-up (the last K slice to arrive adds the tile's partials in slice order), which every
- * call leaves zero again. */
+ * workspace is handed to ppf_gemm_bf16 calls of ONE stream only (every weight gradient recycles it: the 28 MB of partial tiles live and die
+ * in the L2 / memory-side cache); its first 16 KiB are a reserved prefix (the arrival counters of round 3's in-kernel reduce, deleted). */
 size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
 /* Roofline probe of the split-K weight-gradient kernel (epi 6 with a workspace): HIP events (from a reused pool) on the launch

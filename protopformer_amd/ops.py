@@ -33,19 +33,16 @@ _RETIRED_WS = []
 
 
 def _gemm_workspace(device, nbytes):
-    """Split-K scratch of the weight-gradient GEMMs, one per (device, stream), ZERO-FILLED when allocated and used by nothing else:
-    its first 16 KiB are the arrival counters of the in-kernel split-K fix-up, which every call leaves zero again."""
+    """Split-K scratch of the weight-gradient GEMMs, one per (device, stream), used by nothing else: every weight gradient writes its
+    partial tiles into the same 28 MB and the ordered reduce reads them straight back (they stay in the L2 / memory-side cache;
+    giving every GEMM its own range and summing later was measured slower: profiles/r4_reduce_batch.txt)."""
     key = (device, _lib.stream_ptr())
     buf = _GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        # the fill must run on the CONSUMER stream (the weight-gradient lane redirects only the library's launches, torch.zeros would
-        # fill on torch's current stream, unordered against the split-K GEMM that follows on the lane); a buffer that is outgrown stays
-        # allocated: the lane may still be reading it and the allocator knows nothing of that stream
+        # a buffer that is outgrown stays allocated: the lane may still be using it and torch's allocator knows nothing of that stream
         if buf is not None:
             _RETIRED_WS.append(buf)
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        with _lib.unrecorded():
-            _lib.call("ppf_memset_zero", buf, buf.numel())
         _GEMM_WS[key] = buf
     return buf
 
