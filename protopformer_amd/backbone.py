@@ -319,18 +319,31 @@ def deit_backward(ppnet, store, saved, df):
         _lib.run_live(lambda: gs.chunk_ready(gs.tail_chunk, also=lane.streams))
     # The bf16 branch gradient alternates between two buffers: the LayerNorm backward that produces the next one does not have to
     # wait for the side stream's weight-gradient GEMM that still reads the current one (the main stream would otherwise be tied to
-    # the progress of the side stream twice per block).  PPF_DYB_PINGPONG=0: one buffer, overwritten in place.
+    # the progress of the side stream twice per block).  PPF_DYB_PINGPONG=0: one buffer, overwritten in place.  Round 4: four buffers in
+    # rotation instead of two (the side stream lags up to a block behind at the start of backward: +0.6 % deit_small, +0.5 % deit_tiny
+    # same-box; six = four).  Parking the prototype-gradient kernel until a few blocks' weight gradients have run was measured
+    # 1 % SLOWER: at the start of backward it overlaps the serial head section, later it lands in the saturated part.
     pingpong = os.environ.get("PPF_DYB_PINGPONG", "1") != "0"
     dyb_alt = None
+
+    nring = int(os.environ.get("PPF_DYB_RING", "4"))       # buffers the branch gradient rotates through (2 = ping-pong; 4: +0.6 % same-box)
+    ring = {}
 
     def next_dyb(cur, alt):
         if not pingpong:
             lane.before_overwrite(cur)
             return cur, None
-        if alt is None or alt.shape != cur.shape:
-            alt = lane.track(torch.empty_like(cur))
-        lane.before_overwrite(alt)
-        return alt, cur
+        bufs = ring.setdefault(tuple(cur.shape), [cur])
+        if not any(b.data_ptr() == cur.data_ptr() for b in bufs):
+            bufs.append(cur)
+        if len(bufs) < nring:
+            nxt = lane.track(torch.empty_like(cur))
+            bufs.append(nxt)
+        else:
+            i = next(j for j, b in enumerate(bufs) if b.data_ptr() == cur.data_ptr())
+            nxt = bufs[(i + 1) % len(bufs)]
+        lane.before_overwrite(nxt)
+        return nxt, cur
 
     # Bias gradients of proj / fc2 are column sums of the bf16 branch gradient `dyb`: the LayerNorm-backward KERNEL adds them while it
     # writes dyb (dbias_next); the fused GEMM + LayerNorm-backward (csrc/rowgemm.hip) does not, there the weight-gradient GEMM that

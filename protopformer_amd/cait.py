@@ -353,12 +353,20 @@ def cait_backward(ppnet, store, saved, df):
     # The bf16 branch gradient alternates between two buffers (as backbone.deit_backward): the kernel that produces the next one does not
     # wait for the side stream's weight-gradient GEMM that still reads the current one (measured: a 44 us stall per block otherwise).
     dyb_alt = None
+    nring = int(os.environ.get("PPF_DYB_RING", "4"))       # buffers in rotation (2 = ping-pong), as backbone.deit_backward
+    ring = []
 
     def next_dyb(cur, alt):
-        if alt is None:
-            alt = lane.track(torch.empty_like(cur))
-        lane.before_overwrite(alt)
-        return alt, cur
+        if not any(b.data_ptr() == cur.data_ptr() for b in ring):
+            ring.append(cur)
+        if len(ring) < nring:
+            nxt = lane.track(torch.empty_like(cur))
+            ring.append(nxt)
+        else:
+            i = next(j for j, b in enumerate(ring) if b.data_ptr() == cur.data_ptr())
+            nxt = ring[(i + 1) % len(ring)]
+        lane.before_overwrite(nxt)
+        return nxt, cur
 
     for i in range(len(sa) - 1, -1, -1):
         L, blk = sa[i], feats.blocks[i]
