@@ -213,6 +213,7 @@ class WgradLane:
         self.tracked = set()
         self.held = []              # tensors the lane reads, kept alive (so their memory is not reused) until the next join()
         self.pending = []           # deferred launches (fn, reads)
+        self._lane2_tags = set(filter(None, os.environ.get("PPF_LANE2_TAGS", "PROTO").replace("+", ",").split(",")))      # submits that go to the second side stream (PPF_LANES >= 2)
         self._disabled_tags = {k[len("PPF_LANE_"):] for k, v in os.environ.items() if k.startswith("PPF_LANE_") and v == "0"}
 
     def track(self, t):
@@ -224,29 +225,34 @@ class WgradLane:
         if not self.enabled or (tag is not None and tag in self._disabled_tags):
             fn()
             return
-        self.pending.append((fn, reads))
+        self.pending.append((fn, reads, tag))
         self.held.extend(reads)
         if not defer:
-            self.flush(tag)
+            self.flush()
 
     def flush(self, tag=None):
         if not self.pending:
             return
-        # lane 0 carries the weight gradients; the long prototype-gradient kernels at the start of backward (tag "PROTO") get a lane
-        # of their own when there is one, so that the first weight gradients do not queue behind them
-        raw = self.raws[1] if (tag == "PROTO" and len(self.raws) > 1) else self.raws[0]
-        _lib.call("ppf_stream_wait_stream", raw, _lib.stream_ptr())
-        _lib.push_stream(raw)
+        # lane 0 carries the weight gradients; submits whose tag is in PPF_LANE2_TAGS (default: the long prototype-gradient kernels at the
+        # start of backward, "PROTO") go to the second side stream when there is one
+        waited = set()
         try:
-            for fn, reads in self.pending:
-                fn()
-                ptrs = [t.data_ptr() for t in reads if t.data_ptr() in self.tracked]
-                if ptrs:
-                    ticket = _lib.stream_mark(raw)
-                    for q in ptrs:
-                        self.last_read[q] = ticket
+            for fn, reads, tg in self.pending:
+                raw = self.raws[1] if (tg in self._lane2_tags and len(self.raws) > 1) else self.raws[0]
+                if raw not in waited:
+                    _lib.call("ppf_stream_wait_stream", raw, _lib.stream_ptr())
+                    waited.add(raw)
+                _lib.push_stream(raw)
+                try:
+                    fn()
+                    ptrs = [t.data_ptr() for t in reads if t.data_ptr() in self.tracked]
+                    if ptrs:
+                        ticket = _lib.stream_mark(raw)
+                        for q in ptrs:
+                            self.last_read[q] = ticket
+                finally:
+                    _lib.pop_stream()
         finally:
-            _lib.pop_stream()
             self.pending.clear()
 
     def before_overwrite(self, t):
@@ -254,7 +260,7 @@ class WgradLane:
         if t.data_ptr() not in self.tracked:
             raise RuntimeError("WgradLane.before_overwrite: buffer was not registered with track()")
         q = t.data_ptr()
-        if any(r.data_ptr() == q for _, reads in self.pending for r in reads):
+        if any(r.data_ptr() == q for _, reads, _t in self.pending for r in reads):
             self.flush()
         ticket = self.last_read.pop(q, None)
         if ticket is not None:

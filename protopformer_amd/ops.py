@@ -209,7 +209,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, *, dres_in=None, dx_out=None, ro
     if part is not None:
         red = lambda: _lib.call("ppf_layernorm_bwd_reduce", part, rows, D, *sums)
         if lane is not None:
-            lane.submit(red, (part,), defer=defer_reduce)
+            lane.submit(red, (part,), defer=defer_reduce, tag="LNRED")
         else:
             red()
 
