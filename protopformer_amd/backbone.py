@@ -294,6 +294,18 @@ def _wgrad(store, dy16, x16, weight, bias=None):
                                               colsum=gb), (dy16, x16))
 
 
+_DGRAD_NT = os.environ.get("PPF_DGRAD_NT", "1") != "0"
+
+
+def _dgrad(dy16, store, weight, wt):
+    """dx = dy W as bf16.  With the transposed weight shadow (FlatStore.register_transposed) both operands are contraction-contiguous and
+    the product can take the 224 x 128 direct-to-LDS kernel (csrc/gemm_bf16.hip gemm224g_kernel: one round of the chip instead of 1.54 for
+    the N = 384 outputs); otherwise the [K][N] weight is read transposed by the generic kernel.  PPF_DGRAD_NT=0: always the latter (A/B)."""
+    if wt is not None and _DGRAD_NT:
+        return ops.gemm(dy16, wt, epi=EPI_BF16)
+    return ops.gemm(dy16, store.w16(weight), trans_b=True, epi=EPI_BF16)
+
+
 def deit_backward(ppnet, store, saved, df):
     """Backward of image -> f. df: fp32 [B*(1+k), Dp] gradient w.r.t. the sigmoid outputs."""
     feats = ppnet.features
@@ -365,14 +377,18 @@ def deit_backward(ppnet, store, saved, df):
                  and ops.rowgemm_ok(D, D, rpt))
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
         _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias)
-        dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
+        w2t = store.w16t(blk.mlp.fc2.weight) if _DGRAD_NT else None
+        if w2t is not None:      # contraction-contiguous operands: the direct-to-LDS kernel (gemm128g, four workgroups per CU) takes K = 384
+            dh = ops.gemm(dyb, w2t, epi=EPI_DGELU, aux_in=L["h"])
+        else:
+            dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
         _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         dyb, dyb_alt = next_dyb(dyb, dyb_alt)
         if fused:
             ops.rowgemm_lnbwd(dh, w1t, L["x1"], L["mean2"], L["rstd2"], blk.norm2.weight, store.grad_view(blk.norm2.weight), store.grad_view(blk.norm2.bias),
                               rpt, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl, lane=lane, defer_reduce=True)
         else:
-            dn2 = ops.gemm(dh, store.w16(blk.mlp.fc1.weight), trans_b=True, epi=EPI_BF16)
+            dn2 = _dgrad(dh, store, blk.mlp.fc1.weight, w1t)
             lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
                               store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl,
                               dbias_next=store.grad_view(blk.attn.proj.bias))
@@ -382,11 +398,11 @@ def deit_backward(ppnet, store, saved, df):
         if fused:
             dao = ops.rowgemm_bf16(dyb, wpt, rpt)
         else:
-            dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
+            dao = _dgrad(dyb, store, blk.attn.proj.weight, wpt)
         dqkv = (torch.empty_like(L["qkv"]) if "attnbwd" in _KO else
                 ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True, eps_n=L["eps_n"]))
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
-        dn1 = None if fused else ops.gemm(dqkv, store.w16(blk.attn.qkv.weight), trans_b=True, epi=EPI_BF16)
+        dn1 = None if fused else _dgrad(dqkv, store, blk.attn.qkv.weight, wqt)
         if i > 0:
             prev = feats.blocks[i - 1]
             dyb, dyb_alt = next_dyb(dyb, dyb_alt)
@@ -464,8 +480,8 @@ class TokensFn(torch.autograd.Function):
 
 
 def deit_t16_params(feats):
-    """Weights whose input-gradient products read W^T contraction-contiguous (csrc/rowgemm.hip): fc1, qkv, proj of every block."""
-    return [w for blk in feats.blocks for w in (blk.mlp.fc1.weight, blk.attn.qkv.weight, blk.attn.proj.weight)]
+    """Weights whose input-gradient products read W^T contraction-contiguous (csrc/rowgemm.hip, gemm224g / gemm128g): fc1, qkv, proj, fc2."""
+    return [w for blk in feats.blocks for w in (blk.mlp.fc1.weight, blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc2.weight)]
 
 
 DEIT_FNS = dict(embed=deit_embed, blocks=deit_blocks_fwd, backward=deit_backward, t16_params=deit_t16_params)

@@ -420,6 +420,118 @@ int launch_g4_mt(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 224 x 128 tiles for the tall products with a narrow output (round 4): the input-gradient GEMMs dx = dy W of fc1 / qkv / proj have
+// N = 384 output columns, so 128-row tiles give 394 x 3 = 1 182 workgroups for the 768 slots of the chip (three per CU): two rounds,
+// the second 54 % full -- the 23 % tile-quantisation loss of profiles/r2_gemm_knockout.txt.  224-row tiles (seven 32-row MFMA tiles;
+// they need not end on sample boundaries) make it 226 x 3 = 678 workgroups: ONE round, and 81 instead of 64 flops per operand byte.
+// Both operands contraction-contiguous (A = dy [M][K], B = the TRANSPOSED weight shadow [N][K] of FlatStore.register_transposed),
+// fetched by global_load_lds_dwordx4 into a single 44 KiB LDS image (three workgroups per CU overlap each other, as gemm128g);
+// the four waves sit side by side along n: a wave owns all 224 rows x 32 columns (7 accumulator tiles, 112 VGPRs), the A fragments
+// are read by every wave, the B fragment once.  bf16 output only (no bias / fused epilogue: that is what these products need).
+constexpr int G224_ROWS = 224, G224_MT = 7, G224_LD = 36;       // epilogue strip pitch (floats): 32 + 4
+__global__ __launch_bounds__(NTHREADS, 3) void gemm224g_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using IO = TileIO<false, 128>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave * 32;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (vid / tiles_n) * G224_ROWS, n0 = (vid % tiles_n) * BN;
+    unsigned char* tA = smem;
+    unsigned char* tB = smem + G224_ROWS * BK * 2;
+    unsigned offA[G224_MT], offB[4];
+    {
+        const int rb = tid >> 3, ch = (tid & 7) ^ ((rb >> 1) & 7);       // rows rb + 32 i share the swizzle
+#pragma unroll
+        for (int i = 0; i < G224_MT; ++i) offA[i] = ((unsigned)min(m0 + rb + 32 * i, p.M - 1) * (unsigned)p.lda + ch * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offB[i] = ((unsigned)min(n0 + rb + 32 * i, p.N - 1) * (unsigned)p.ldb + ch * 8) * 2u;
+    }
+    const unsigned char* gA = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* gB = reinterpret_cast<const unsigned char*>(p.B);
+    f32x16 acc[G224_MT];
+#pragma unroll
+    for (int j = 0; j < G224_MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = p.K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();                          // everyone finished reading the previous K tile
+        const unsigned char* ka = gA + (size_t)kt * (BK * 2);
+        const unsigned char* kb = gB + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < G224_MT; ++i)
+            __builtin_amdgcn_global_load_lds((g4_gbl_t*)(ka + offA[i]), (g4_lds_t*)(tA + i * 4096 + wave * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((g4_gbl_t*)(kb + offB[i]), (g4_lds_t*)(tB + i * 4096 + wave * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const bf16x8 fb = IO::frag(tB, wn, ks, lane);
+#pragma unroll
+            for (int mi = 0; mi < G224_MT; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, IO::frag(tA, 32 * mi, ks, lane), acc[mi], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // a lane holds row 32 mi + (lane & 31) and, for g = 0..3, columns wn + 8 g + 4 (lane >> 5) + 0..3: through a per-wave strip so that
+    // four lanes store one row's 32 columns as 16-byte pieces
+    const int h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * G224_LD);
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+    for (int mi = 0; mi < G224_MT; ++mi) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(stage + (lane & 31) * G224_LD + 8 * g + 4 * h) =
+                make_float4(acc[mi][4 * g], acc[mi][4 * g + 1], acc[mi][4 * g + 2], acc[mi][4 * g + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = pass * 16 + (lane >> 2), col = (lane & 3) * 8;
+            const int m = m0 + 32 * mi + r, n = n0 + wn + col;
+            const float4 a = *reinterpret_cast<const float4*>(stage + r * G224_LD + col);
+            const float4 b = *reinterpret_cast<const float4*>(stage + r * G224_LD + col + 4);
+            if (m < p.M && n < p.N)
+                *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + n) = make_uint4(pack_bf16x2(a.x * p.alpha, a.y * p.alpha), pack_bf16x2(a.z * p.alpha, a.w * p.alpha),
+                                                                                 pack_bf16x2(b.x * p.alpha, b.y * p.alpha), pack_bf16x2(b.z * p.alpha, b.w * p.alpha));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Takes a plain bf16-output NT product when 224-row tiles need fewer rounds of the chip's 3-per-CU slots than 128-row tiles do.
+bool g224_eligible(const GemmParams& p, int epi) {
+    static const int mode = getenv("PPF_GEMM_G224") ? atoi(getenv("PPF_GEMM_G224")) : 1;
+    if (!mode || epi != EPI_BF16 || p.bias != nullptr || p.kpad || p.K % BK != 0 || p.N % 8 != 0 || (p.ldc & 7) != 0) return false;
+    if ((long long)p.M * p.lda >= (1ll << 30) || (long long)p.N * p.ldb >= (1ll << 30)) return false;
+    if (mode == 2) return true;
+    static const int slots = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return 3 * (n > 0 ? n : 256); }();
+    const long long tn = (p.N + BN - 1) / BN;
+    const long long t128 = (long long)((p.M + BM - 1) / BM) * tn, t224 = (long long)((p.M + G224_ROWS - 1) / G224_ROWS) * tn;
+    const long long r128 = (t128 + slots - 1) / slots * BM, r224 = (t224 + slots - 1) / slots * G224_ROWS;      // rounds x rows per round
+    return t128 >= slots && r224 < r128;
+}
+int launch_g224(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = G224_ROWS * BK * 2 + TILE_BYTES;           // 28 + 16 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm224g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(gemm224g): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + G224_ROWS - 1) / G224_ROWS) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm224g_kernel, dim3(tiles), dim3(NTHREADS), lds, stream, p);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
 // MT = 4 (256x128 workgroup tiles, 128x64 per wave: 25 % fewer LDS fragment bytes per MFMA) was measured SLOWER at three and at two
 // workgroups per CU (qkv 60.6 -> 83.6 / 69.0 us, fc1+GELU 132 -> 155 / 146 us, train step -5.4 % / -1.9 %; profiles/r2_gemm_knockout.txt):
 // what these K = 384 GEMMs want is more independent workgroups per CU, not fewer LDS bytes.  Only MT = 2 is instantiated.
@@ -598,6 +710,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
     if (!trans_a && !trans_b) {
         if (nt256_eligible(p, epi)) return launch_nt256(p, epi, stream);
+        if (g224_eligible(p, epi)) return launch_g224(p, stream);
         if (g4_eligible(p)) {
             switch (epi) {
                 case EPI_BF16: return launch_g4<EPI_BF16>(p, stream);

@@ -128,3 +128,21 @@ def test_gemm_wgrad_train_step_shapes():
     lines = r.stdout.strip().splitlines()
     assert all("repeatable True" in l for l in lines if l.startswith("dW")), r.stdout
     assert float(lines[-1].split()[-1]) < 1e-4, r.stdout
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 384, 1536), (50432, 384, 384), (20992, 384, 1152), (5000, 256, 128)])
+def test_gemm_224_row_tiles_nt(M, N, K):
+    """The 224 x 128 direct-to-LDS kernel (input gradients with the transposed weight shadow, PPF_GEMM_G224=2 forces it for every shape in a
+    child process): bf16 output vs an fp32 reference, edge tiles in m, bit-identical repeats."""
+    from protopformer_amd import ops
+    a = _mk((M, K), 0.5, 1).bfloat16(); b = _mk((N, K), 0.1, 2).bfloat16()
+    out = ops.gemm(a, b, epi=ops.EPI_BF16)
+    ref = a.float() @ b.float().t()
+    assert_close(out.float(), ref, rtol=8e-3, atol=2e-3 * float(ref.abs().max()), what="nt 224")
+    for _ in range(3):
+        assert torch.equal(out, ops.gemm(a, b, epi=ops.EPI_BF16))
+    # transpose-detecting: an asymmetric pattern
+    a2 = torch.zeros(448, 64, device="cuda"); a2[:, 0] = torch.arange(448, device="cuda") % 17 - 8.0
+    b2 = torch.zeros(128, 64, device="cuda"); b2[:, 0] = torch.arange(128, device="cuda") % 5 - 2.0
+    o2 = ops.gemm(a2.bfloat16(), b2.bfloat16(), epi=ops.EPI_BF16).float()
+    assert torch.equal(o2, (a2[:, :1] @ b2[:, :1].t()))
