@@ -275,7 +275,11 @@ def _mlp_bwd(store, blk, L, dyb, fc2_bias=False, want_dn=True):
     output (the caller then fuses fc1's input gradient with the LayerNorm backward).  fc2_bias: dyb's producer did not accumulate
     fc2.bias' gradient, the weight-gradient GEMM that reads dyb anyway sums its columns."""
     _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias if fc2_bias else None)
-    dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
+    w2t = store.w16t(blk.mlp.fc2.weight)
+    if w2t is not None:          # contraction-contiguous operands: the direct-to-LDS kernels (csrc/gemm_bf16.hip gemm224g / gemm128g)
+        dh = ops.gemm(dyb, w2t, epi=EPI_DGELU, aux_in=L["h"])
+    else:
+        dh = ops.gemm(dyb, store.w16(blk.mlp.fc2.weight), trans_b=True, epi=EPI_DGELU, aux_in=L["h"])
     _wgrad(store, dh, L["n2"], blk.mlp.fc1.weight, blk.mlp.fc1.bias)
     if not want_dn:
         return dh
@@ -423,7 +427,7 @@ def cait_backward(ppnet, store, saved, df):
 
 def cait_t16_params(feats):
     """Weights whose input-gradient products read W^T contraction-contiguous (csrc/rowgemm.hip): fc1, qkv, proj of the talking-heads blocks."""
-    return [w for blk in feats.blocks for w in (blk.mlp.fc1.weight, blk.attn.qkv.weight, blk.attn.proj.weight)]
+    return [w for blk in feats.blocks for w in (blk.mlp.fc1.weight, blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc2.weight)]
 
 
 CAIT_FNS = dict(embed=cait_embed, blocks=cait_blocks_fwd, backward=cait_backward, t16_params=cait_t16_params)

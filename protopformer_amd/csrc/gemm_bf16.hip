@@ -506,17 +506,29 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm224g_kernel(const GemmParams 
     }
 }
 
-// Takes a plain bf16-output NT product when 224-row tiles need fewer rounds of the chip's 3-per-CU slots than 128-row tiles do.
+// Takes a plain bf16-output NT product when 224-row tiles (three workgroups per CU) need less CU time than 128-row tiles (three per CU in
+// the generic kernel, four in the direct-to-LDS one); a partly filled last round is priced as a whole round (a round lasts a tile's
+// latency however many CUs it fills: 1.54 rounds measured as 2), half a round below 25 % fill.  K >= 384: with three K tiles per
+// workgroup (the D = 192 models) the larger tile's prologue / epilogue outweigh the saved round -- fc1 + GELU and the x gelu' input
+// gradient of deit_tiny / cait_xxs24 (N = 768, K = 192; 1 182 vs 678 tiles) were measured 1.1 % SLOWER per step with this kernel.
+bool g4_eligible(const GemmParams& p);
 bool g224_eligible(const GemmParams& p, int epi) {
     static const int mode = getenv("PPF_GEMM_G224") ? atoi(getenv("PPF_GEMM_G224")) : 1;
     if (!mode || epi != EPI_BF16 || p.bias != nullptr || p.kpad || p.K % BK != 0 || p.N % 8 != 0 || (p.ldc & 7) != 0) return false;
     if ((long long)p.M * p.lda >= (1ll << 30) || (long long)p.N * p.ldb >= (1ll << 30)) return false;
     if (mode == 2) return true;
-    static const int slots = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return 3 * (n > 0 ? n : 256); }();
+    if (p.K < 384) return false;
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long long tn = (p.N + BN - 1) / BN;
     const long long t128 = (long long)((p.M + BM - 1) / BM) * tn, t224 = (long long)((p.M + G224_ROWS - 1) / G224_ROWS) * tn;
-    const long long r128 = (t128 + slots - 1) / slots * BM, r224 = (t224 + slots - 1) / slots * G224_ROWS;      // rounds x rows per round
-    return t128 >= slots && r224 < r128;
+    const int per128 = g4_eligible(p) ? 4 : 3;
+    auto cost = [](long long tiles, long long slots, int rows, int per) {          // CU time in row units
+        const long long full = tiles / slots, rest = tiles - full * slots;
+        double c = (double)full * rows * per;
+        if (rest) c += rows * per * (4 * rest >= slots ? 1.0 : 0.5);
+        return c;
+    };
+    return t128 >= (long long)per128 * cus && cost(t224, 3ll * cus, G224_ROWS, 3) < 0.97 * cost(t128, (long long)per128 * cus, BM, per128);
 }
 int launch_g224(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = G224_ROWS * BK * 2 + TILE_BYTES;           // 28 + 16 KiB
