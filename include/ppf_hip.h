@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 6
+#define PPF_ABI_VERSION 7
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -208,7 +208,17 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
 int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
                   float eps, const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok,
                   int64_t dstride_b, float* dprotos, void* zeroed_workspace, size_t workspace_bytes, ppf_stream_t stream);
-/* (workspace: B*T*ceil(P/32)*4 bytes, zero-filled by the caller: bitmap of the non-zero dL/dd entries) */
+/* workspace: ppf_proto_bwd_workspace() bytes = [bitmap of the non-zero dL/dd entries, B*T*ceil(P/32)*4 bytes rounded up to 256, present
+ * and ZERO-FILLED by the caller when dtok != NULL][scratch of the prototype gradients when dprotos != NULL, any content].  A workspace
+ * that only holds the bitmap is accepted: the prototype gradients then take the per-prototype gather kernel (same results to rounding). */
+size_t ppf_proto_bwd_workspace(int B, int T, int P, int Dp, int want_dtok, int want_dprotos);
+/* The same backward with the activation-map gradient in the block form get_PPC_loss produces (protopformer.py:259-288: only the ppc
+ * prototypes of the sample's own class get a gradient): g_rows [B][ppc][T] = dL/d act_full[b][label[b]*ppc + k][t]; every other entry
+ * of the (B,P,T) gradient is zero and is never materialised.  label_i64: int64 labels [B] (0 <= label*ppc <= P - ppc). */
+int ppf_proto_bwd_rows(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
+                       float eps, const float* dist_full, const float* g_rows, const void* label_i64, int ppc, const float* g_max,
+                       const int* argmax, float* dtok, int64_t dstride_b, float* dprotos, void* workspace, size_t workspace_bytes,
+                       ppf_stream_t stream);
 /* T == 1 (global branch, protopformer.py:295,311 and its autograd): dense form of the same backward -- two fp32 products instead of the
  * gather.  g [B][P] = upstream gradient of the activations, dist [B][P]; dtok rows are overwritten (when non-null), dprotos accumulated. */
 size_t ppf_proto_bwd_single_workspace(int B, int P, int Dp);

@@ -36,6 +36,7 @@ SIGS = {
     "ppf_rollout_threshold": "p" "iiii" "p" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",
+    "ppf_proto_bwd_rows": "pliip" "iiii" "f" "ppp" "i" "ppp" "l" "p" "pz" "s",
     "ppf_proto_bwd_single": "plip" "iiii" "f" "ppp" "l" "p" "pz" "s",
     "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
     "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",
@@ -80,7 +81,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 6               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 7               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
@@ -108,6 +109,8 @@ def lib():
         _lib.ppf_sgemm_pair_workspace.argtypes = [ctypes.c_int] * 5
         _lib.ppf_proto_bwd_single_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_bwd_single_workspace.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_proto_bwd_workspace.restype = ctypes.c_size_t
+        _lib.ppf_proto_bwd_workspace.argtypes = [ctypes.c_int] * 6
         _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int
         _lib.ppf_layernorm_bwd_blocks.argtypes = [ctypes.c_int]
         _lib.ppf_sigmoid_bwd_blocks.restype = ctypes.c_int

@@ -600,46 +600,36 @@ int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) 
 // one-thread-per-position loop read its 12-98 slabs one dependent load after the other (22 us for a 192x192 gradient of 98 slabs).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, float* __restrict__ colsum,
                                                             int M, int N, int ldc, int nsplit, int cs_parts) {
-    __shared__ float4 part[3][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // round 4: ONE lane per float4 position with up to sixteen slab loads in flight (a weight gradient has 12-48 slabs; the round-3 form
+    // gave each of four waves a quarter of the slabs -- three loads in flight per lane at 12 slabs -- and combined through LDS behind a
+    // barrier).  Slabs are added in ascending order within groups of sixteen: fixed order, bit-identical from run to run.
     const size_t mn = (size_t)M * N, slice = mn + (colsum ? (size_t)cs_parts * M : 0);
     const size_t total4 = mn / 4;
-    const size_t i = (size_t)blockIdx.x * 64 + lane;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < total4) {
         const float* p = ws + i * 4;
-        int z = w;
-        for (; z + 12 < nsplit; z += 16) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)z * slice);
-            const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(z + 4) * slice);
-            const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(z + 8) * slice);
-            const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(z + 12) * slice);
-            acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
-            acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z0 = 0; z0 < nsplit; z0 += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int z = min(z0 + u, nsplit - 1);                      // branch-free: past the end re-reads the last slab (not added)
+                v[u] = *reinterpret_cast<const float4*>(p + (size_t)z * slice);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z0 + u < nsplit) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
-        for (; z < nsplit; z += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)z * slice);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-    } else if (colsum && i < total4 + (size_t)M) {
-        const size_t m = i - total4;
-        for (int z = w; z < nsplit; z += 4)
-            for (int q = 0; q < cs_parts; ++q) acc.x += ws[(size_t)z * slice + mn + (size_t)q * M + m];
-    }
-    if (w) part[w - 1][lane] = acc;
-    __syncthreads();
-    if (w) return;
-    for (int q = 0; q < 3; ++q) {
-        const float4 v = part[q][lane];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    if (i < total4) {
         const size_t e = i * 4, m = e / N, n = e - m * N;
         float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
         const float4 c = *dst;
         *dst = make_float4(c.x + acc.x, c.y + acc.y, c.z + acc.z, c.w + acc.w);
     } else if (colsum && i < total4 + (size_t)M) {
-        colsum[i - total4] += acc.x;
+        const size_t m = i - total4;
+        float a = 0.f;
+        for (int z = 0; z < nsplit; ++z)
+            for (int q = 0; q < cs_parts; ++q) a += ws[(size_t)z * slice + mn + (size_t)q * M + m];
+        colsum[m] += a;
     }
 }
 
@@ -771,7 +761,7 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                     g_probe.bytes += 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N;
                 }
                 const size_t work = (size_t)M * N / 4 + (colsum ? M : 0);
-                const int grid = (int)((work + 63) / 64);
+                const int grid = (int)((work + 255) / 256);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p.ws, (float*)C, colsum, M, N, ldc, ns, p.cs_parts);
                 PPF_LAUNCH_CHECK();
                 return 0;

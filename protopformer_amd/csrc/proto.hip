@@ -358,6 +358,9 @@ struct ProtoBwdParams {
     int act_kind; float eps;
     const float* dist_full;    // [B][P][T]
     const float* g_full;       // [B][P][T] upstream grad of act_full, or null
+    const float* g_rows;       // [B][ppc][T] or null: the same gradient in block form -- sample b's rows are the prototypes
+    const long long* row_label;//   row_label[b]*ppc ... +ppc-1 (the PPC loss touches nothing else); added to g_full when both are given
+    int ppc;
     const float* g_max;        // [B][P]    upstream grad of act_max, or null
     const int* argmax;         // [B][P] (null when T == 1)
     float* dtok;               // written: row(b,i) = dtok + b*dstride_b + (t0+i)*Dp
@@ -374,6 +377,10 @@ __device__ __forceinline__ float dact_dd(float d, int kind, float eps) {
 __device__ __forceinline__ float grad_d(const ProtoBwdParams& p, int b, int pi, int t, int amax, float gmax) {
     const size_t o = ((size_t)b * p.P + pi) * p.T + t;
     float g = p.g_full ? p.g_full[o] : 0.f;
+    if (p.g_rows) {
+        const int k = pi - (int)p.row_label[b] * p.ppc;
+        if (k >= 0 && k < p.ppc) g += p.g_rows[((size_t)b * p.ppc + k) * p.T + t];
+    }
     if (t == amax) g += gmax;
     if (g == 0.f) return 0.f;
     return g * dact_dd(p.dist_full[o], p.act_kind, p.eps);
@@ -415,11 +422,36 @@ __global__ __launch_bounds__(256) void proto_bwd_mark_kernel(const ProtoBwdParam
                 if (src[f] != 0.f) { const int pl = f / T, t = f - pl * T; atomicOr(&bm[((size_t)b * T + t) * W + w], 1u << pl); }
         }
     }
+    if (p.g_rows) {
+        const int k0 = 32 * w - (int)p.row_label[b] * p.ppc;                    // block row of this word's first prototype
+        if (k0 + np > 0 && k0 < p.ppc)
+        for (int i = threadIdx.x; i < np * T; i += 256) {
+            const int pl = i / T, t = i - pl * T, k = k0 + pl;
+            if (k >= 0 && k < p.ppc && p.g_rows[((size_t)b * p.ppc + k) * T + t] != 0.f) atomicOr(&bm[((size_t)b * T + t) * W + w], 1u << pl);
+        }
+    }
     if (p.g_max && threadIdx.x < np) {
         const size_t bp = (size_t)b * p.P + 32 * w + threadIdx.x;
         if (p.g_max[bp] != 0.f) {
             const int am = p.argmax ? p.argmax[bp] : 0;
             atomicOr(&bm[((size_t)b * T + am) * W + w], 1u << threadIdx.x);
+        }
+    }
+}
+// The same bitmap when there is no dense g_full: one workgroup per sample marks the arg-max token of every prototype and the non-zero
+// entries of the sample's block rows (B workgroups instead of B * P / 32 nearly empty ones).
+__global__ __launch_bounds__(256) void proto_bwd_mark_sparse_kernel(const ProtoBwdParams p, uint32_t* __restrict__ bm, int W) {
+    const int b = blockIdx.x, T = p.T;
+    if (p.g_max)
+        for (int pi = threadIdx.x; pi < p.P; pi += 256) {
+            const size_t bp = (size_t)b * p.P + pi;
+            if (p.g_max[bp] != 0.f) atomicOr(&bm[((size_t)b * T + (p.argmax ? p.argmax[bp] : 0)) * W + (pi >> 5)], 1u << (pi & 31));
+        }
+    if (p.g_rows) {
+        const int p0 = (int)p.row_label[b] * p.ppc;
+        for (int i = threadIdx.x; i < p.ppc * T; i += 256) {
+            const int k = i / T, t = i - k * T, pi = p0 + k;
+            if (pi >= 0 && pi < p.P && p.g_rows[((size_t)b * p.ppc + k) * T + t] != 0.f) atomicOr(&bm[((size_t)b * T + t) * W + (pi >> 5)], 1u << (pi & 31));
         }
     }
 }
@@ -543,6 +575,10 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdPa
                 if (e < E) {
                     const size_t bp = (size_t)b * p.P + pi;
                     if (p.g_full) g[u] = p.g_full[bp * p.T + t];
+                    if (p.g_rows) {
+                        const int k = pi - (int)p.row_label[b] * p.ppc;
+                        if (k >= 0 && k < p.ppc) g[u] += p.g_rows[((size_t)b * p.ppc + k) * p.T + t];
+                    }
                     if (p.g_max) { const int am = p.argmax ? p.argmax[bp] : 0; if (t == am) g[u] += p.g_max[bp]; }
                 }
             }
@@ -618,6 +654,205 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdPa
     }
 }
 
+// ---- prototype gradients, tiled form (round 4).  The per-prototype kernel above gathers one 1.5 KiB token row per non-zero dL/dd
+// entry straight from memory: B*P arg-max rows + the label rows, 1.1 GB per step for the 2000 x 256 x 81 case although the token tensor
+// itself is 32 MB.  Here the roles are swapped.
+//  arg-max terms (proto_bwd_protos_tiled_kernel): a workgroup keeps the accumulators of 256 prototypes in registers (16 waves x 16
+//    prototypes x Dp floats), walks a group of samples and has each sample's token block brought into LDS once (LDS-DMA, two chunk
+//    images: the next chunk streams in while the current one is used), so a token row is fetched P/256 times instead of once per entry.
+//    With  dprotos[p] = sum 2 G (p - x) = 2 (sum G) p - 2 sum G x  a wave accumulates  sum G x  (rows read from LDS) and  sum G  per
+//    prototype; the finish kernel adds the sample groups' partials in ascending order and forms the difference.
+//  block rows (proto_bwd_protos_rows_kernel, gradient given as g_rows): one workgroup per sample; wave k owns prototype label*ppc + k,
+//    the token block is staged the same way and every token contributes 2 G (p - x) to a per-sample partial row; the finish kernel adds
+//    the partial rows of a class's samples in ascending order.  These (sample, prototype) pairs are left out of the tiled kernel.
+// Deterministic: every prototype's terms are added in a fixed order, no float atomics.  A dense g_full keeps the per-prototype kernel.
+typedef __attribute__((address_space(3))) void pt_lds_void;
+typedef const __attribute__((address_space(1))) void pt_gbl_void;
+constexpr int PT_NW = 16;
+// LDS-DMA copy of rows [r0, r0 + rows) of sample b's token block into image `dst` (1 KiB per wave instruction).
+__device__ __forceinline__ void pt_issue_chunk(const ProtoBwdParams& p, int b, int r0, int rows, unsigned char* dst, int wave, int lane) {
+    const int bytes = rows * p.Dp * 4;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.tok + (size_t)b * p.stride_b + (size_t)(p.t0 + r0) * p.Dp);
+    for (int i = wave; i * 1024 < bytes; i += PT_NW) {
+        const int off = min(i * 1024 + lane * 16, bytes - 16);                 // the last wave-row re-reads the final 16 bytes
+        __builtin_amdgcn_global_load_lds((pt_gbl_void*)(src + off), (pt_lds_void*)(dst + i * 1024), 16, 0, 0);
+    }
+}
+template <int NJ, int SLOTS>
+__global__ __launch_bounds__(1024) void proto_bwd_protos_tiled_kernel(const ProtoBwdParams p, float* __restrict__ part, float* __restrict__ psum,
+                                                                       int pt, int nsg, int spg, int R, int nchunks, int chunk_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // workgroup -> (prototype tile, sample group): dispatch id L runs on XCD L % 8, and the pt workgroups that read the same samples
+    // should share an L2 -- consecutive slots of ONE XCD take the tiles of a group (the token tensor then leaves HBM once, not pt times)
+    int tile = blockIdx.x % pt, grp = blockIdx.x / pt;
+    if (gridDim.x % 8 == 0 && nsg % 8 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = j % pt; grp = xcd * (nsg >> 3) + j / pt;
+    }
+    const int pw0 = tile * (PT_NW * SLOTS) + wave * SLOTS;
+    const int nvalid = min(SLOTS, p.P - pw0);                              // <= 0: this wave only helps with the copies
+    const int b0 = grp * spg, b1 = min(p.B, b0 + spg);
+    const int T = p.T, Dp = p.Dp;
+    float acc[SLOTS][NJ];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[s][j] = 0.f;
+    float sg = 0.f;                                                        // lane s < SLOTS: sum of G for prototype pw0 + s
+    const int nsteps = (b1 - b0) * nchunks;
+    if (nsteps > 0) pt_issue_chunk(p, b0, 0, min(R, T), pt_smem, wave, lane);
+    int am = 0; float G = 0.f;
+    for (int s = 0; s < nsteps; ++s) {
+        const int bi = s / nchunks, c = s - bi * nchunks, b = b0 + bi;
+        const int r0 = c * R, rows = min(R, T - r0);
+        if (c == 0) {                                                      // new sample: coefficients of this wave's prototypes
+            am = 0; G = 0.f;
+            if (lane < nvalid) {
+                const int pi = pw0 + lane;
+                const size_t bp = (size_t)b * p.P + pi;
+                const float gm = p.g_max[bp];
+                bool mine = gm != 0.f;
+                if (p.g_rows) { const int k = pi - (int)p.row_label[b] * p.ppc; mine = mine && !(k >= 0 && k < p.ppc); }
+                if (mine) {
+                    am = p.argmax[bp];
+                    G = gm * dact_dd(p.dist_full[bp * T + am], p.act_kind, p.eps);
+                    sg += G;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's share of chunk s has landed ...
+        __syncthreads();                                                   // ... everyone's has, and image (s+1)&1 is no longer read
+        if (s + 1 < nsteps) {
+            const int bi2 = (s + 1) / nchunks, c2 = s + 1 - bi2 * nchunks;
+            pt_issue_chunk(p, b0 + bi2, c2 * R, min(R, T - c2 * R), pt_smem + ((s + 1) & 1) * chunk_pad, wave, lane);
+        }
+        const float* X = reinterpret_cast<const float*>(pt_smem + (s & 1) * chunk_pad);
+        if (nvalid > 0) {
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int t = __builtin_amdgcn_readlane(am, sl) - r0;
+                const float Gs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(G), sl));
+                if (Gs != 0.f && t >= 0 && t < rows) {
+                    const float* xr = X + t * Dp;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; acc[sl][j] += Gs * (d < Dp ? xr[d] : 0.f); }
+                }
+            }
+        }
+    }
+    if (nvalid > 0) {
+        float* out = part + ((size_t)grp * p.P + pw0) * Dp;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+            if (sl < nvalid) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < Dp) out[(size_t)sl * Dp + d] = acc[sl][j]; }
+            }
+        if (lane < nvalid) psum[(size_t)grp * p.P + pw0 + lane] = sg;
+    }
+}
+// Block rows of ONE sample per workgroup: wave k < ppc owns prototype label*ppc + k and writes  sum_t 2 G (p - x[b,t])  to rpart[b][k][:].
+template <int NJ>
+__global__ __launch_bounds__(1024) void proto_bwd_protos_rows_kernel(const ProtoBwdParams p, float* __restrict__ rpart, int R, int nchunks, int chunk_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x, T = p.T, Dp = p.Dp;
+    const int pi = (int)p.row_label[b] * p.ppc + wave;
+    const bool owner = wave < p.ppc && pi >= 0 && pi < p.P;
+    pt_issue_chunk(p, b, 0, min(R, T), pt_smem, wave, lane);
+    float pv[NJ], acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; pv[j] = (owner && d < Dp) ? p.protos[(size_t)pi * Dp + d] : 0.f; acc[j] = 0.f; }
+    const size_t bp = (size_t)b * p.P + (owner ? pi : 0);
+    const int am = (owner && p.argmax && p.g_max) ? p.argmax[bp] : -1;
+    const float gm = (owner && p.g_max) ? p.g_max[bp] : 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int r0 = c * R, rows = min(R, T - r0);
+        // coefficients of this chunk's tokens (R <= 128 rows starting anywhere in a 64-block: three per lane), loaded ahead of the
+        // wait so they travel with the chunk
+        float Gt[3] = {0.f, 0.f, 0.f};
+        const int th0 = r0 & ~63;
+        if (owner) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const int t = th0 + 64 * h + lane;
+                const bool in = t >= r0 && t < r0 + rows;
+                float g = in ? p.g_rows[((size_t)b * p.ppc + wave) * T + t] : 0.f;
+                if (in && t == am) g += gm;
+                Gt[h] = (g != 0.f) ? 2.0f * g * dact_dd(p.dist_full[bp * T + t], p.act_kind, p.eps) : 0.f;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nchunks) pt_issue_chunk(p, b, (c + 1) * R, min(R, T - (c + 1) * R), pt_smem + ((c + 1) & 1) * chunk_pad, wave, lane);
+        if (!owner) continue;
+        const float* X = reinterpret_cast<const float*>(pt_smem + (c & 1) * chunk_pad);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            unsigned long long m = __ballot(Gt[h] != 0.f);
+            while (m) {
+                const int l = __builtin_ctzll(m); m &= m - 1;
+                const float Gs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Gt[h]), l));
+                const float* xr = X + (th0 + 64 * h + l - r0) * Dp;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; acc[j] += Gs * (pv[j] - (d < Dp ? xr[d] : 0.f)); }
+            }
+        }
+    }
+    if (owner) {
+        float* out = rpart + ((size_t)b * p.ppc + wave) * Dp;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int d = lane + 64 * j; if (d < Dp) out[d] = acc[j]; }
+    }
+}
+// dprotos[p][:] += 2 ((sum_g psum[g][p]) protos[p][:] - sum_g part[g][p][:])  (sample groups ascending; skipped when part == null)
+//               +  sum over the samples b of class p / ppc, ascending, of rpart[b][p % ppc][:]   (skipped when rpart == null)
+__global__ __launch_bounds__(128) void proto_bwd_protos_finish_kernel(const float* __restrict__ part, const float* __restrict__ psum,
+                                                                      const float* __restrict__ rpart, const long long* __restrict__ label, int ppc,
+                                                                      const float* __restrict__ protos, float* __restrict__ dprotos, int B, int P, int Dp, int SG) {
+    const int pi = blockIdx.x, lane = threadIdx.x & 63;
+    const size_t n = (size_t)P * Dp;
+    float add[3] = {0.f, 0.f, 0.f};                                        // d = threadIdx.x + 128 q  (Dp <= 384)
+    if (part) {
+        float sgv = 0.f;
+        for (int g = 0; g < SG; ++g) sgv += psum[(size_t)g * P + pi];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int d = threadIdx.x + 128 * q;
+            if (d < Dp) {
+                const size_t i = (size_t)pi * Dp + d;
+                float a = 0.f;
+                int g = 0;
+                for (; g + 8 <= SG; g += 8) {                                  // eight loads in flight, added in ascending order
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(g + u) * n + i];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a += v[u];
+                }
+                for (; g < SG; ++g) a += part[(size_t)g * n + i];
+                add[q] = 2.0f * (sgv * protos[i] - a);
+            }
+        }
+    }
+    if (rpart) {
+        const int cls = pi / ppc, k = pi - cls * ppc;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            unsigned long long m = __ballot(b0 + lane < B && (int)label[b0 + lane] == cls);
+            while (m) {
+                const int b = b0 + __builtin_ctzll(m); m &= m - 1;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const int d = threadIdx.x + 128 * q; if (d < Dp) add[q] += rpart[((size_t)b * ppc + k) * Dp + d]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const int d = threadIdx.x + 128 * q; if (d < Dp) dprotos[(size_t)pi * Dp + d] += add[q]; }
+}
+
 // ---- T == 1 (the global / cls branch): every (sample, prototype) pair carries a gradient, so the gather form degenerates into two
 // dense fp32 products  dtok[b] = 2 (sum_p G[b,p]) tok[b] - 2 G protos,   dprotos[p] += 2 (sum_b G[b,p]) protos[p] - 2 G^T tok
 // with G[b,p] = g[b,p] * dact/dd(dist[b,p]).
@@ -668,6 +903,28 @@ __global__ __launch_bounds__(256) void proto_single_fixup_kernel(float* __restri
     }
 }
 
+// Geometry of the tiled prototype-gradient form (proto_bwd_protos_tiled_kernel); ok == false: the per-prototype gather kernel runs.
+struct ProtoTiled { bool ok; int slots, pt, sg, spg, R, nchunks, chunk_pad; size_t ws_bytes; };
+ProtoTiled proto_tiled_geometry(int B, int T, int P, int Dp, int64_t stride_b, int t0) {
+    ProtoTiled g{};
+    static const int mode = getenv("PPF_PROTO_TILED") ? atoi(getenv("PPF_PROTO_TILED")) : 1;
+    static const int sg_env = getenv("PPF_PROTO_SG") ? atoi(getenv("PPF_PROTO_SG")) : 0;
+    if (!mode || T < 2 || Dp % 4 || Dp > 384 || stride_b % 4 || ((int64_t)t0 * Dp) % 4) return g;
+    const int row_bytes = Dp * 4, rmax = min(128, (76 * 1024) / row_bytes);  // two images of <= 76 KiB, <= 128 rows each
+    g.slots = 16;                                                            // 16 x 6 accumulator registers per lane at Dp = 384
+    g.nchunks = (T + rmax - 1) / rmax;
+    g.R = (T + g.nchunks - 1) / g.nchunks;
+    g.chunk_pad = ((g.R * row_bytes + 1023) / 1024) * 1024;
+    g.pt = (P + PT_NW * g.slots - 1) / (PT_NW * g.slots);
+    int sg = sg_env > 0 ? sg_env : (256 + g.pt - 1) / g.pt;                  // about one workgroup per CU
+    if (sg > B) sg = B;
+    g.spg = (B + sg - 1) / sg;
+    g.sg = (B + g.spg - 1) / g.spg;
+    g.ws_bytes = ((size_t)g.sg * P * Dp + (size_t)g.sg * P + (size_t)B * PT_NW * Dp) * sizeof(float);     // part, psum, rpart (ppc <= 16)
+    g.ok = true;
+    return g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -711,30 +968,49 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
     return 0;
 }
 
-// Backward of ppf_proto_fwd given upstream grads of act_max (g_max) and act_full (g_full), either may be null.
+// Backward of ppf_proto_fwd given upstream grads of act_max (g_max) and act_full (g_full and / or its block form g_rows), any may be null.
 // dtok rows are overwritten; dprotos [P][Dp] is accumulated (+=).
-int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
-                  const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok, int64_t dstride_b,
-                  float* dprotos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    PPF_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && Dp > 0 && T >= 1 && Dp <= 512, PPF_ERR_SHAPE, "ppf_proto_bwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
-    PPF_CHECK_ARG(tok && protos && dist_full && (g_full || g_max) && (T == 1 || argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd: null pointer");
+static int proto_bwd_launch(ProtoBwdParams p, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const int B = p.B, P = p.P, Dp = p.Dp, T = p.T;
     const int W = (P + 31) / 32;
-    const size_t need = (size_t)B * T * W * sizeof(uint32_t);
-    PPF_CHECK_ARG(dtok == nullptr || (workspace != nullptr && workspace_bytes >= need), PPF_ERR_ARG,
-                  "ppf_proto_bwd: needs a ZEROED workspace of B*T*ceil(P/32)*4 = %zu bytes", need);
-    ProtoBwdParams p;
-    p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
-    p.dist_full = dist_full; p.g_full = g_full; p.g_max = g_max; p.argmax = (T == 1) ? nullptr : argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
+    const size_t need = p.dtok ? (((size_t)B * T * W * sizeof(uint32_t) + 255) & ~(size_t)255) : 0;
+    PPF_CHECK_ARG(p.dtok == nullptr || (workspace != nullptr && workspace_bytes >= (size_t)B * T * W * sizeof(uint32_t)), PPF_ERR_ARG,
+                  "ppf_proto_bwd: needs a ZEROED workspace of B*T*ceil(P/32)*4 = %zu bytes", (size_t)B * T * W * sizeof(uint32_t));
+    // prototype gradients: the tiled form when there is no dense g_full and the caller's workspace has room for its partial sums
+    ProtoTiled tg = (p.dprotos && !p.g_full && (!p.g_max || p.argmax)) ? proto_tiled_geometry(B, T, P, Dp, p.stride_b, p.t0) : ProtoTiled{};
+    if (tg.ok && p.g_rows && p.ppc > PT_NW) tg.ok = false;
+    if (tg.ok && !(workspace && workspace_bytes >= need + tg.ws_bytes && ((uintptr_t)p.tok & 15) == 0)) tg.ok = false;
     const int nj = (Dp + 63) / 64;
     auto run = [&](auto njc) {
         constexpr int NJ = decltype(njc)::value;
-        if (dtok) {
-            hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(W, B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
+        if (p.dtok) {
+            if (p.g_full) hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(W, B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
+            else hipLaunchKernelGGL(proto_bwd_mark_sparse_kernel, dim3(B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
             static const int tok_nw = getenv("PPF_PROTO_TOK_NW") ? atoi(getenv("PPF_PROTO_TOK_NW")) : 1;
             if (W <= 64 && tok_nw == 1) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 1>), dim3(B * T), dim3(64), 0, stream, p, (const uint32_t*)workspace, W);
             else hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 8>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
         }
-        if (dprotos) {
+        if (p.dprotos && tg.ok) {
+            if constexpr (NJ <= 6) {
+                const int lds = 2 * tg.chunk_pad;
+                static int attr_lds = 0;
+                if (lds > attr_lds) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proto_bwd_protos_tiled_kernel<NJ, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(proto_bwd_protos_rows_kernel<NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    attr_lds = lds;
+                }
+                float* part = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + need);
+                float* psum = part + (size_t)tg.sg * P * Dp;
+                float* rpart = psum + (size_t)tg.sg * P;
+                if (p.g_max)
+                    hipLaunchKernelGGL((proto_bwd_protos_tiled_kernel<NJ, 16>), dim3(tg.pt * tg.sg), dim3(1024), lds, stream, p, part, psum, tg.pt, tg.sg,
+                                       tg.spg, tg.R, tg.nchunks, tg.chunk_pad);
+                if (p.g_rows)
+                    hipLaunchKernelGGL((proto_bwd_protos_rows_kernel<NJ>), dim3(B), dim3(1024), lds, stream, p, rpart, tg.R, tg.nchunks, tg.chunk_pad);
+                hipLaunchKernelGGL(proto_bwd_protos_finish_kernel, dim3(P), dim3(128), 0, stream, p.g_max ? part : nullptr, psum, p.g_rows ? rpart : nullptr,
+                                   p.row_label, p.ppc, p.protos, p.dprotos, B, P, Dp, tg.sg);
+            }
+        } else if (p.dprotos) {
             constexpr int lds = PB_NW * PB_CHUNK * 6 + PB_NW * NJ * 64 * 4 + (PB_NW + 1) * 4;
             static bool attr_set = false;
             if (!attr_set) {
@@ -752,6 +1028,42 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
     else run(std::integral_constant<int, 8>());
     PPF_LAUNCH_CHECK();
     return 0;
+}
+
+int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
+                  const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok, int64_t dstride_b,
+                  float* dprotos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && Dp > 0 && T >= 1 && Dp <= 512, PPF_ERR_SHAPE, "ppf_proto_bwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
+    PPF_CHECK_ARG(tok && protos && dist_full && (g_full || g_max) && (T == 1 || argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd: null pointer");
+    ProtoBwdParams p;
+    p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
+    p.dist_full = dist_full; p.g_full = g_full; p.g_rows = nullptr; p.row_label = nullptr; p.ppc = 0; p.g_max = g_max;
+    p.argmax = (T == 1) ? nullptr : argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
+    return proto_bwd_launch(p, workspace, workspace_bytes, stream);
+}
+
+// The same backward with the activation-map gradient in the block form the PPC loss produces (protopformer.py:259-288: only the ppc
+// prototypes of a sample's own class receive a gradient): g_rows [B][ppc][T] holds dL/d act_full[b][label[b]*ppc + k][t], every other
+// entry of the (B,P,T) gradient is zero and is never materialised, scanned or stored.  Same workspace contract as ppf_proto_bwd.
+int ppf_proto_bwd_rows(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
+                       const float* dist_full, const float* g_rows, const void* label_i64, int ppc, const float* g_max, const int* argmax,
+                       float* dtok, int64_t dstride_b, float* dprotos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    PPF_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && Dp > 0 && T >= 2 && Dp <= 512 && ppc >= 1 && ppc <= P, PPF_ERR_SHAPE,
+                  "ppf_proto_bwd_rows: bad shape B=%d P=%d Dp=%d T=%d ppc=%d", B, P, Dp, T, ppc);
+    PPF_CHECK_ARG(tok && protos && dist_full && g_rows && label_i64 && (argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd_rows: null pointer");
+    ProtoBwdParams p;
+    p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
+    p.dist_full = dist_full; p.g_full = nullptr; p.g_rows = g_rows; p.row_label = (const long long*)label_i64; p.ppc = ppc; p.g_max = g_max;
+    p.argmax = argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
+    return proto_bwd_launch(p, workspace, workspace_bytes, stream);
+}
+
+// Bytes of workspace ppf_proto_bwd wants: the zeroed bitmap (when token gradients are asked for) followed by the scratch of the tiled
+// prototype-gradient form (need not be initialised; a smaller workspace selects the per-prototype gather kernel instead).
+size_t ppf_proto_bwd_workspace(int B, int T, int P, int Dp, int want_dtok, int want_dprotos) {
+    const size_t bm = want_dtok ? (((size_t)B * T * ((P + 31) / 32) * sizeof(uint32_t) + 255) & ~(size_t)255) : 0;
+    const ProtoTiled tg = want_dprotos ? proto_tiled_geometry(B, T, P, Dp, 0, 0) : ProtoTiled{};
+    return bm + (tg.ok ? tg.ws_bytes : 0);
 }
 
 int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int ldc,

@@ -319,7 +319,9 @@ def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_
     return act_max, argmax, dist, act
 
 
-def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4):
+def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4, rows=None):
+    """Backward of proto_fwd.  g_full [B,P,T] is the dense gradient of the activation maps; rows = (g_rows [B,ppc,T], label int64 [B], ppc)
+    gives the same gradient in the block form of the PPC loss instead (ppf_proto_bwd_rows: nothing of shape (B,P,T) is touched)."""
     B, Ttot, Dp = tokens.shape
     P = protos.shape[0]
     if T == 1 and (g_full is None) != (g_max is None) and os.environ.get("PPF_PROTO_BWD_DENSE", "1") != "0":
@@ -328,9 +330,21 @@ def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos,
         _lib.call("ppf_proto_bwd_single", tokens, Ttot * Dp, t0, protos, B, P, Dp, act_kind, float(eps), dist, g_max if g_max is not None else g_full,
                   dtok, Ttot * Dp, dprotos, ws, ws.numel())
         return
-    bitmap = zeros((B, T, (P + 31) // 32), torch.int32, tokens.device) if dtok is not None else None
+    need = _lib.lib().ppf_proto_bwd_workspace(B, T, P, Dp, int(dtok is not None), int(dprotos is not None))
+    if dtok is not None:
+        ws = torch.empty(need, dtype=torch.uint8, device=tokens.device)
+        _lib.call("ppf_memset_zero", ws, _lib.lib().ppf_proto_bwd_workspace(B, T, P, Dp, 1, 0))     # the bitmap; the scratch behind it is write-first
+    else:
+        ws = _workspace(tokens.device, need) if need else None    # prototype gradients only: per-stream scratch, any content
+    if rows is not None:
+        if g_full is not None:
+            raise ValueError("proto_bwd: pass the activation-map gradient either dense (g_full) or in block form (rows), not both")
+        g_rows, label, ppc = rows
+        _lib.call("ppf_proto_bwd_rows", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_rows, label, int(ppc), g_max, argmax,
+                  dtok, Ttot * Dp, dprotos, ws, need)
+        return
     _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_full, g_max, argmax, dtok,
-              Ttot * Dp, dprotos, bitmap, bitmap.numel() * 4 if bitmap is not None else 0)
+              Ttot * Dp, dprotos, ws, need)
 
 
 def ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh):
@@ -343,6 +357,25 @@ def ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh):
     loss = torch.empty(2, dtype=torch.float32, device=dev)
     _lib.call("ppf_ppc_loss", act, idx, label, B, P, T, ppc, side, float(cov_thresh), float(mean_thresh), partial, gcov, gmean, loss)
     return loss, gcov, gmean
+
+
+def ppc_loss_bwd_rows(gcov, gmean, up_cov, up_mean):
+    """up_cov * gcov + up_mean * gmean as [B, ppc, T]: the PPC gradient in block form (row k of sample b belongs to prototype label[b]*ppc + k)."""
+    B, ppc, T = gcov.shape
+    rows = torch.empty_like(gcov)
+    _lib.call("ppf_ppc_loss_bwd", gcov, gmean, up_cov, up_mean, _zero_labels(gcov.device, B), rows, B, ppc, T, ppc)
+    return rows
+
+
+_ZERO_LABELS = {}
+
+
+def _zero_labels(device, B):
+    t = _ZERO_LABELS.get(device)
+    if t is None or t.numel() < B:
+        t = zeros((max(B, 1024),), torch.int64, device)
+        _ZERO_LABELS[device] = t
+    return t
 
 
 def ppc_loss_bwd(gcov, gmean, up_cov, up_mean, label, P):

@@ -56,6 +56,48 @@ def build_features(base_architecture, pretrained=False, img_size=224, drop_path=
 _SIDE_FIRST = os.environ.get("PPF_PROTO_SIDE_FIRST", "1") != "0"
 
 
+# The PPC loss only sends a gradient to the ppc prototypes of each sample's own class.  Instead of scattering it into a dense (B,P,T)
+# tensor that the prototype-layer backward would scan twice, PPCLossFn.backward hands autograd a zero-stride placeholder of that shape
+# and parks the block rows here, keyed by the placeholder's storage; ProtoLayerFn.backward picks them up (ppf_proto_bwd_rows).  Only taken
+# when the activation map comes straight (through views) from ProtoLayerFn; a gradient that autograd had to combine with another one
+# is detected below and reported -- PPF_PROTO_ROWS=0 restores the dense exchange.
+_PROTO_ROWS = os.environ.get("PPF_PROTO_ROWS", "1") != "0"
+_PENDING_ROWS = {}
+
+
+def _rows_for(g_full):
+    """(rows, label, ppc) parked for this gradient, or None when it is an ordinary dense tensor."""
+    if not _PENDING_ROWS:
+        return None
+    hit = _PENDING_ROWS.pop(g_full.data_ptr(), None) if g_full is not None and not any(g_full.stride()) else None
+    if hit is None:
+        _PENDING_ROWS.clear()
+        raise RuntimeError("protopformer_amd: the block-form PPC gradient did not reach the prototype layer unchanged (the activation map "
+                           "has another consumer in this graph); set PPF_PROTO_ROWS=0 to exchange dense gradients")
+    return hit[1:]
+
+
+def _check_rows_consumed():
+    if _PENDING_ROWS:
+        _PENDING_ROWS.clear()
+        raise RuntimeError("protopformer_amd: a block-form PPC gradient was produced but no prototype-layer backward consumed it; "
+                           "set PPF_PROTO_ROWS=0 to exchange dense gradients")
+
+
+def _from_proto_layer(t):
+    fn = t.grad_fn
+    for _ in range(4):                                    # through reshape / view nodes
+        if fn is None:
+            return False
+        if type(fn).__name__ == "ProtoLayerFnBackward":
+            return True
+        nxt = [f for f, _ in fn.next_functions if f is not None]
+        if len(nxt) != 1 or "View" not in type(fn).__name__ and "Reshape" not in type(fn).__name__:
+            return False
+        fn = nxt[0]
+    return False
+
+
 class ProtoLayerFn(torch.autograd.Function):
     """get_activations for both branches (protopformer.py:236-247, 311-312)."""
 
@@ -88,22 +130,25 @@ class ProtoLayerFn(torch.autograd.Function):
         store.attach_all_grads()
         B, T1, Dp = f.shape
         # every token row is written when both branches carry a gradient (the local rows 1.., the cls row 0): no zero fill then
-        full = (g_l is not None or g_full is not None) and g_g is not None
+        full = (g_l is not None or g_full is not None) and g_g is not None        # (a block-form g_full is a placeholder tensor, not None)
         df = torch.empty(f.shape, dtype=f.dtype, device=f.device) if full else ops.zeros(f.shape, f.dtype, f.device)
         lane = wgrad_lane(store)      # prototype gradients feed only the optimizer: side stream, under the backbone backward
         torch.autograd.Variable._execution_engine.queue_callback(lane.join)     # ... joined when this backward pass ends
-        if g_l is not None or g_full is not None:
+        rows = _rows_for(g_full)
+        if rows is not None:
+            g_full = None
+        if g_l is not None or g_full is not None or rows is not None:
             gf = g_full.contiguous() if g_full is not None else None
             gl = g_l.contiguous() if g_l is not None else None
             pl = protos_local.reshape(-1, Dp)
             # the side stream starts on the prototype gradients BEFORE the main stream's token-gradient kernels are enqueued: the two
             # only share inputs, and the lane orders itself behind whatever the main stream has enqueued at submit time
             side_l = lambda: ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, None, store.grad_view(protos_local).reshape(-1, Dp),
-                                           act_kind, ppnet.epsilon)
-            reads_l = [t for t in (f, dist, gf, gl, argmax) if t is not None]
+                                           act_kind, ppnet.epsilon, rows=rows)
+            reads_l = [t for t in (f, dist, gf, gl, argmax) + (rows[:2] if rows is not None else ()) if t is not None]
             if _SIDE_FIRST:
                 lane.submit(side_l, reads_l, tag="PROTO")
-            ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, df, None, act_kind, ppnet.epsilon)
+            ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, df, None, act_kind, ppnet.epsilon, rows=rows)
             if not _SIDE_FIRST:
                 lane.submit(side_l, reads_l, tag="PROTO")
         if g_g is not None:
@@ -157,6 +202,7 @@ class PPCLossFn(torch.autograd.Function):
         loss, gcov, gmean = ops.ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh)
         ctx.save_for_backward(gcov, gmean, label)
         ctx.shape = act_full.shape
+        ctx.block_rows = _PROTO_ROWS and ppc <= 16 and act.shape[2] >= 2 and _from_proto_layer(act_full)
         ctx.set_materialize_grads(False)
         return loss[0], loss[1]
 
@@ -165,6 +211,12 @@ class PPCLossFn(torch.autograd.Function):
         gcov, gmean, label = ctx.saved_tensors
         uc = up_cov.reshape(1).float().contiguous() if up_cov is not None else None
         um = up_mean.reshape(1).float().contiguous() if up_mean is not None else None
+        if ctx.block_rows:
+            rows = ops.ppc_loss_bwd_rows(gcov, gmean, uc, um)
+            holder = torch.empty(1, dtype=gcov.dtype, device=gcov.device)             # never read: its storage address is the key
+            _PENDING_ROWS[holder.data_ptr()] = (holder, rows, label, gcov.shape[1])
+            torch.autograd.Variable._execution_engine.queue_callback(_check_rows_consumed)
+            return holder.expand(ctx.shape), None, None, None, None, None, None
         g_full = ops.ppc_loss_bwd(gcov, gmean, uc, um, label, ctx.shape[1])
         return g_full.reshape(ctx.shape), None, None, None, None, None, None
 

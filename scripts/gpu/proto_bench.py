@@ -48,4 +48,15 @@ for b in range(B):
 gmax = torch.randn(B, P, generator=g).cuda()
 t_tok = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, gfull, gmax, argmax, dtok, None))
 t_pro = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, gfull, gmax, argmax, None, dpro))
-print(f"T=81 backward: d tokens (mark + gather) {t_tok:7.1f} us | d prototypes {t_pro:7.1f} us")
+print(f"T=81 backward: d tokens (mark + gather) {t_tok:7.1f} us | d prototypes {t_pro:7.1f} us   (PPF_PROTO_TILED={os.environ.get('PPF_PROTO_TILED', '1')}"
+      f" PPF_PROTO_SG={os.environ.get('PPF_PROTO_SG', 'auto')})")
+gz = torch.zeros_like(gfull)
+t_z = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, gz, gmax, argmax, None, dpro))
+t_n = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, None, gmax, argmax, None, dpro))
+print(f"   d prototypes with an all-zero g_full {t_z:7.1f} us | without g_full {t_n:7.1f} us")
+# block-row form of the same gradient (what the train step uses): nothing of shape (B,P,T) is scanned
+rows = torch.full((B, 10, T), 0.01, device="cuda")
+blk = (rows, lab.cuda(), 10)
+t_tok = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, None, gmax, argmax, dtok, None, rows=blk))
+t_pro = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, None, gmax, argmax, None, dpro, rows=blk))
+print(f"T=81 backward, block rows: d tokens {t_tok:7.1f} us | d prototypes {t_pro:7.1f} us")

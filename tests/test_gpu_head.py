@@ -105,7 +105,7 @@ def test_proto_fwd_golden_and_kat():
     assert torch.equal(torch.gather(act, 2, argmax.long()[..., None])[..., 0], act_max)
 
 
-@pytest.mark.parametrize("B,T,Dp,P", [(3, 9, 32, 20), (2, 121, 192, 200), (130, 1, 64, 50), (4, 81, 384, 300)])
+@pytest.mark.parametrize("B,T,Dp,P", [(3, 9, 32, 20), (2, 121, 192, 200), (130, 1, 64, 50), (4, 81, 384, 300), (300, 9, 32, 20), (2, 121, 384, 40)])
 def test_proto_fwd_bwd_vs_oracle(B, T, Dp, P):
     from protopformer_amd import ops
     g = torch.Generator().manual_seed(T)
@@ -126,6 +126,52 @@ def test_proto_fwd_bwd_vs_oracle(B, T, Dp, P):
     ops.proto_bwd(tokens.cuda(), t0, T, protos.cuda(), dist, gfull.cuda(), gmax.cuda(), argmax, dtok, dpro)
     assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens")
     assert_close(dpro, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes")
+
+
+@pytest.mark.parametrize("B,T,Dp,P,ppc", [(5, 9, 32, 20, 2), (3, 121, 192, 200, 10), (6, 81, 384, 300, 10), (300, 9, 64, 40, 4), (2, 121, 384, 48, 16),
+                                          (4, 16, 100, 60, 20)])
+def test_proto_bwd_block_rows_vs_oracle(B, T, Dp, P, ppc):
+    """ppf_proto_bwd_rows: the activation-map gradient given as the PPC loss's [B, ppc, T] block rows (prototypes label*ppc .. +ppc-1 of each
+    sample) against autograd of the oracle fed the equivalent dense (B,P,T) gradient -- token and prototype gradients, together and in
+    the two separate calls the train step makes (token gradients on the main stream, prototype gradients on the side stream)."""
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(T + ppc)
+    tokens = torch.rand(B, T + 1, Dp, generator=g)
+    protos = torch.rand(P, Dp, generator=g)
+    label = torch.randint(0, P // ppc, (B,), generator=g)
+    if B >= 5:
+        label[3] = label[1]                                                          # two samples of one class: ordered accumulation
+    rows = torch.randn(B, ppc, T, generator=g)
+    rows[:, :, ::3] = 0.0                                                            # exact zeros inside the block, as the hinge terms leave
+    gmax = torch.randn(B, P, generator=g)
+    gmax[:, 1] = 0.0
+    gfull = torch.zeros(B, P, T)
+    for b in range(B):
+        gfull[b, int(label[b]) * ppc: int(label[b]) * ppc + ppc] = rows[b]
+    xt = tokens.clone().requires_grad_(True); pr = protos.clone().requires_grad_(True)
+    mx, d_ref, a_ref = O.proto_activations(xt[:, 1:1 + T], pr)
+    ((mx * gmax).sum() + (a_ref * gfull).sum()).backward()
+    act_max, argmax, dist, act = ops.proto_fwd(tokens.cuda(), 1, T, protos.cuda())
+    cu = lambda t: t.cuda()
+    blk = (cu(rows), cu(label), ppc)
+    dtok = torch.zeros(B, T + 1, Dp, device="cuda"); dpro = torch.zeros(P, Dp, device="cuda")
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, cu(gmax), argmax, dtok, dpro, rows=blk)
+    assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens (block rows)")
+    assert_close(dpro, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes (block rows)")
+    dtok2 = torch.zeros_like(dtok); dpro2 = torch.zeros_like(dpro)
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, cu(gmax), argmax, dtok2, None, rows=blk)
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, cu(gmax), argmax, None, dpro2, rows=blk)
+    assert torch.equal(dtok2, dtok) and torch.equal(dpro2, dpro), "separate calls differ from the combined one"
+    # the dense form of the same gradient agrees to rounding (different summation order)
+    dtok3 = torch.zeros_like(dtok); dpro3 = torch.zeros_like(dpro)
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, cu(gfull), cu(gmax), argmax, dtok3, dpro3)
+    assert_close(dtok3, dtok, rtol=1e-4, atol=1e-5 * float(dtok.abs().max()), what="dense vs block form, tokens")
+    assert_close(dpro3, dpro, rtol=1e-3, atol=2e-5 * float(dpro.abs().max()), what="dense vs block form, prototypes")
+    # rows only (no max-pool gradient)
+    dpro4 = torch.zeros_like(dpro); dpro5 = torch.zeros_like(dpro)
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, None, None, None, dpro4, rows=blk)
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, cu(gfull), None, None, None, dpro5)
+    assert_close(dpro4, dpro5, rtol=1e-3, atol=2e-5 * float(dpro5.abs().max()), what="rows only")
 
 
 def test_ppc_loss_golden_and_grad():
