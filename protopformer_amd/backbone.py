@@ -283,15 +283,23 @@ def wgrad_lane(store):
     return lane
 
 
-def _wgrad(store, dy16, x16, weight, bias=None):
+# Every non-deferred submit costs the MAIN stream one event-record packet (the side stream waits for it), and a packet boundary is
+# 4-9 us of main-queue time (profiles/r4_queue_gaps.txt).  The first weight gradient of each branch (fc2, proj) is therefore parked and
+# launched together with the second one (fc1, qkv) under a single record: two records per block instead of four -- for the narrow
+# models (embed dim <= 256: deit_tiny +1.8 % same-box, cait_xxs24 +-0), whose kernels are short against the packet boundaries; at
+# D = 384 the later start of the parked GEMM costs more than the records (-0.5 %).  PPF_WGRAD_DEFER=0 / 1: never / always.
+_WGRAD_DEFER = os.environ.get("PPF_WGRAD_DEFER", "auto")
+
+
+def _wgrad(store, dy16, x16, weight, bias=None, defer=False):
     """dW[N,K] += dy^T x (deterministic split-K into the flat grad), optional fused bias grad (column sums of dy); queued on
-    the weight-gradient lane."""
+    the weight-gradient lane (defer: launched with the next submit, see above)."""
     if "wgrad" in _KO:
         return
     gw = store.grad_view(weight)
     gb = store.grad_view(bias) if bias is not None else None
     wgrad_lane(store).submit(lambda: ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
-                                              colsum=gb), (dy16, x16))
+                                              colsum=gb), (dy16, x16), defer=defer and (_WGRAD_DEFER == "1" or (_WGRAD_DEFER == "auto" and min(weight.shape[0], weight.shape[1]) <= 256)))
 
 
 _DGRAD_NT = os.environ.get("PPF_DGRAD_NT", "1") != "0"
@@ -376,7 +384,7 @@ def deit_backward(ppnet, store, saved, df):
         fused = (_row_bwd(B * Nl, D) and w1t is not None and wqt is not None and wpt is not None and ops.rowgemm_ok(D, hid, rpt) and ops.rowgemm_ok(D, 3 * D, rpt)
                  and ops.rowgemm_ok(D, D, rpt))
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
-        _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias)
+        _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias, defer=True)
         w2t = store.w16t(blk.mlp.fc2.weight) if _DGRAD_NT else None
         if w2t is not None:      # contraction-contiguous operands: the direct-to-LDS kernel (gemm128g, four workgroups per CU) takes K = 384
             dh = ops.gemm(dyb, w2t, epi=EPI_DGELU, aux_in=L["h"])
@@ -394,7 +402,7 @@ def deit_backward(ppnet, store, saved, df):
                               dbias_next=store.grad_view(blk.attn.proj.bias))
         bias_done = not fused
         # attention branch: x1 = x + s1 * (attn(n1) Wp^T + bp)
-        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, None if bias_done else blk.attn.proj.bias)
+        _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, None if bias_done else blk.attn.proj.bias, defer=True)
         if fused:
             dao = ops.rowgemm_bf16(dyb, wpt, rpt)
         else:

@@ -274,7 +274,7 @@ def _mlp_bwd(store, blk, L, dyb, fc2_bias=False, want_dn=True):
     """Shared MLP backward: consumes dyb = bf16 gradient of the fc2 output; returns dn2 bf16 (want_dn) or dh, the gradient at fc1's
     output (the caller then fuses fc1's input gradient with the LayerNorm backward).  fc2_bias: dyb's producer did not accumulate
     fc2.bias' gradient, the weight-gradient GEMM that reads dyb anyway sums its columns."""
-    _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias if fc2_bias else None)
+    _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, blk.mlp.fc2.bias if fc2_bias else None, defer=True)
     w2t = store.w16t(blk.mlp.fc2.weight)
     if w2t is not None:          # contraction-contiguous operands: the direct-to-LDS kernels (csrc/gemm_bf16.hip gemm224g / gemm128g)
         dh = ops.gemm(dyb, w2t, epi=EPI_DGELU, aux_in=L["h"])
@@ -380,7 +380,7 @@ def cait_backward(ppnet, store, saved, df):
             ops.rowgemm_lnbwd(dh, store.w16t(blk.mlp.fc1.weight), L["x1"], L["mean2"], L["rstd2"], blk.norm2.weight, gv(blk.norm2.weight), gv(blk.norm2.bias),
                               rptb, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=N, lane=lane, defer_reduce=True,
                               colscale=blk.gamma_1, branch=L["raw1"], dcolscale=gv(blk.gamma_1))
-            _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, blk.attn.proj.bias)
+            _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, blk.attn.proj.bias, defer=True)
             dao = ops.rowgemm_bf16(dyb, store.w16t(blk.attn.proj.weight), rptb)
         else:
             dn2 = _mlp_bwd(store, blk, L, dyb, fc2_bias=not bias_done)
@@ -388,7 +388,7 @@ def cait_backward(ppnet, store, saved, df):
             lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], gv(blk.norm2.weight), gv(blk.norm2.bias), dres_in=dx, dx_out=dx,
                               cast_out=dyb, rowscale=L["s1"], rows_per_group=N, colscale=blk.gamma_1, dbias_next=gv(blk.attn.proj.bias),
                               branch=L["raw1"], dcolscale=gv(blk.gamma_1))
-            _wgrad(store, dyb, L["ao"], blk.attn.proj.weight)
+            _wgrad(store, dyb, L["ao"], blk.attn.proj.weight, defer=True)
             dao = ops.gemm(dyb, store.w16(blk.attn.proj.weight), trans_b=True, epi=EPI_BF16)
         dqkv = _th_attention_bwd(store, blk, L, dao, B, H, N, D)
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)

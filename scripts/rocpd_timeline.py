@@ -43,19 +43,21 @@ def main(path):
         before = [short(r[0]) for r in step if r[2] == ge][:1]
         after = [short(r[0]) for r in step if r[1] == gs][:1]
         print(f"  gap {1e-3 * g:8.1f} us  after {before}  before {after}")
-    # per-queue idle: gaps between consecutive kernels of the busiest queue (the main stream), by (previous -> next) kernel pair
-    mainq = max(qs, key=lambda q: qs[q][0])
-    mq = sorted((r[1], r[2], r[0]) for r in step if r[3] == mainq)
-    pair, tot = {}, 0
-    for (s0, e0, n0), (s1, e1, n1) in zip(mq, mq[1:]):
-        g = s1 - e0
-        if g > 0:
-            tot += g
-            k = (short(n0)[:34], short(n1)[:34])
-            pair.setdefault(k, [0, 0]); pair[k][0] += 1; pair[k][1] += g
-    print(f"main queue {mainq}: idle between its own kernels {1e-6 * tot:.3f} ms in {len(mq) - 1} gaps")
-    for k, (n, g) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:16]:
-        print(f"  {1e-3 * g:8.1f} us total, {n:3d} x {1e-3 * g / n:6.1f} us   {k[0]}  ->  {k[1]}")
+    # per-queue idle: gaps between consecutive kernels of a queue, by (previous -> next) kernel pair; the busiest queue is the main stream
+    for rank, q in enumerate(sorted(qs, key=lambda q: -qs[q][0])):
+        mq = sorted((r[1], r[2], r[0]) for r in step if r[3] == q)
+        pair, tot = {}, 0
+        for (s0, e0, n0), (s1, e1, n1) in zip(mq, mq[1:]):
+            g = s1 - e0
+            if g > 0:
+                tot += g
+                k = (short(n0)[:34], short(n1)[:34])
+                pair.setdefault(k, [0, 0]); pair[k][0] += 1; pair[k][1] += g
+        span = mq[-1][1] - mq[0][0]
+        print(f"{'main' if rank == 0 else 'side'} queue {q}: idle between its own kernels {1e-6 * tot:.3f} ms in {len(mq) - 1} gaps "
+              f"(first kernel to last: {1e-6 * span:.3f} ms)")
+        for k, (n, g) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:16 if rank == 0 else 10]:
+            print(f"  {1e-3 * g:8.1f} us total, {n:3d} x {1e-3 * g / n:6.1f} us   {k[0]}  ->  {k[1]}")
     # overlap: time with >= 2 kernels running
     pts = sorted([(s, 1) for s, e in ev] + [(e, -1) for s, e in ev])
     depth, last, two = 0, None, 0
