@@ -352,13 +352,18 @@ def deit_backward(ppnet, store, saved, df):
     pingpong = os.environ.get("PPF_DYB_PINGPONG", "1") != "0"
     dyb_alt = None
 
-    nring = int(os.environ.get("PPF_DYB_RING", "4"))       # buffers the branch gradient rotates through (2 = ping-pong; 4: +0.6 % same-box)
+    # buffers the branch gradient rotates through (2 = ping-pong; 4: +0.6 % same-box at D = 384).  The narrow models never reuse one
+    # (64 > two per block): their side stream lags whole blocks behind and every reuse is a main-stream wait (cait_xxs24 +4 % same-box,
+    # deit_tiny +0.2 %; 24-48 buffers of B*N*D bf16 = 0.2-0.5 GB of the 288); at D = 384 no reuse measured -0.7 % (larger footprint).
+    nring = int(os.environ.get("PPF_DYB_RING", "4" if D > 256 else "64"))
     ring = {}
 
     def next_dyb(cur, alt):
         if not pingpong:
             lane.before_overwrite(cur)
             return cur, None
+        if nring >= 64:                                   # never reused: nothing to order against the side stream, no marks
+            return torch.empty_like(cur), cur
         bufs = ring.setdefault(tuple(cur.shape), [cur])
         if not any(b.data_ptr() == cur.data_ptr() for b in bufs):
             bufs.append(cur)

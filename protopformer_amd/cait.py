@@ -357,10 +357,12 @@ def cait_backward(ppnet, store, saved, df):
     # The bf16 branch gradient alternates between two buffers (as backbone.deit_backward): the kernel that produces the next one does not
     # wait for the side stream's weight-gradient GEMM that still reads the current one (measured: a 44 us stall per block otherwise).
     dyb_alt = None
-    nring = int(os.environ.get("PPF_DYB_RING", "4"))       # buffers in rotation (2 = ping-pong), as backbone.deit_backward
+    nring = int(os.environ.get("PPF_DYB_RING", "4" if D > 256 else "64"))       # buffers in rotation, as backbone.deit_backward (narrow: no reuse)
     ring = []
 
     def next_dyb(cur, alt):
+        if nring >= 64:                                    # never reused: nothing to order against the side stream, no marks
+            return torch.empty_like(cur), cur
         if not any(b.data_ptr() == cur.data_ptr() for b in ring):
             ring.append(cur)
         if len(ring) < nring:
