@@ -43,7 +43,13 @@ bool g_ring_made[RING];
 int64_t g_seq = 0;
 hipEvent_t ring_event(int64_t seq) {
     const int i = (int)(seq % RING);
-    if (!g_ring_made[i]) { (void)hipEventCreateWithFlags(&g_ring[i], hipEventDisableTiming); g_ring_made[i] = true; }
+    if (!g_ring_made[i]) {
+        // ordering between two streams of ONE device: no timestamps and no system-scope fence (the host never inspects these events,
+        // agent scope is what a kernel boundary gives anyway).  PPF_EVENT_SYSFENCE=1 restores the default system-scope release.
+        static const bool sysfence = getenv("PPF_EVENT_SYSFENCE") && atoi(getenv("PPF_EVENT_SYSFENCE")) != 0;
+        (void)hipEventCreateWithFlags(&g_ring[i], hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence));
+        g_ring_made[i] = true;
+    }
     return g_ring[i];
 }
 }  // namespace
