@@ -132,7 +132,8 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
                     ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
                 if side_thr and "thr" not in _KO:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
-            lane.submit(side, (qkv, rowmax, zinv, hm, thr))
+            # (PPF_ROLLOUT_BATCH = n: the side launches of n consecutive layers go out under one main-stream event record)
+            lane.submit(side, (qkv, rowmax, zinv, hm, thr), defer=(i % _ROLL_BATCH != _ROLL_BATCH - 1) and i != reserve_layer - 1)
             if roll_side and i == reserve_layer - 1:
                 # the rollout chain (176 us, one workgroup per sample) depends only on the head-mean maps and thresholds the lane has
                 # produced: it runs there, right behind the last map, under the rest of this block instead of in front of the next one
@@ -289,6 +290,7 @@ def wgrad_lane(store):
 # models (embed dim <= 256: deit_tiny +1.8 % same-box, cait_xxs24 +-0), whose kernels are short against the packet boundaries; at
 # D = 384 the later start of the parked GEMM costs more than the records (-0.5 %).  PPF_WGRAD_DEFER=0 / 1: never / always.
 _WGRAD_DEFER = os.environ.get("PPF_WGRAD_DEFER", "auto")
+_ROLL_BATCH = max(1, int(os.environ.get("PPF_ROLLOUT_BATCH", "3")))      # 3: +0.9 % deit_tiny, +0.6 % deit_small same-box against 1
 
 
 def _wgrad(store, dy16, x16, weight, bias=None, defer=False):

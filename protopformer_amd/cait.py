@@ -149,11 +149,13 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     rowk = (os.environ.get("PPF_CAIT_ROWGEMM", "1") != "0" and bool(feats.blocks) and ops.rowgemm_ok(D, D, rpt)
             and ops.rowgemm_ok(D, feats.blocks[0].mlp.fc1.out_features, rpt))
     pre = None
+    rb = max(1, int(os.environ.get("PPF_ROLLOUT_BATCH", "3")))
     for i, blk in enumerate(feats.blocks):
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, prob, a16 = _th_attention_fwd(blk, qkv, B, H, N, D, hm[i])
-        lane.submit(lambda i=i: ops.rollout_threshold(hm[i], thr[i], N), (hm, thr))      # the rollout's order statistic, off the critical path
+        # the rollout's order statistic, off the critical path (three layers per main-stream event record, as backbone.forward_blocks)
+        lane.submit(lambda i=i: ops.rollout_threshold(hm[i], thr[i], N), (hm, thr), defer=(i % rb != rb - 1) and i != len(feats.blocks) - 1)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         if rowk:
