@@ -664,7 +664,10 @@ int pick_splitk(int M, int N, int K) {
     // K slices: alone on the GPU the kernel is fastest with as many slices as fit in ONE round of 3 workgroups per CU (768:
     // -17 % vs 540; one slice more spills into a second round and gives it all back).  In the train step these GEMMs run on
     // the side stream under the dgrad chain, where a smaller footprint wins (step time: 432 <= 540 < 768), so that is the default.
-    static const int target = getenv("PPF_SPLITK_TARGET") ? atoi(getenv("PPF_SPLITK_TARGET")) : 432;
+    // Narrow layers (an output side <= 256: the D = 192 models) take half as many: their reduce kernel reads every slab back and is a
+    // third of the side stream's time there (216: deit_tiny +1.5 %, cait_xxs24 +2.9 % same-box; 144: -2 %; at D = 384 288: -4 %).
+    static const int target_env = getenv("PPF_SPLITK_TARGET") ? atoi(getenv("PPF_SPLITK_TARGET")) : 0;
+    const int target = target_env > 0 ? target_env : (min(M, N) <= 256 ? 216 : 432);
     int s = target / tiles;
     const int maxs = (K + 4 * BK - 1) / (4 * BK);      // at least 4 K-tiles per slice
     if (s > maxs) s = maxs;
