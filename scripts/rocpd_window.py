@@ -1,8 +1,6 @@
-"""Serial sections of the last train step in a rocprofv3 rocpd database: every kernel of both queues between the last forward block
-and the first backward block (the prototype / loss head), and around the optimizer, with start offsets and durations."""
-import re
-import sqlite3
-import sys
+"""Kernels of all queues around the n-th occurrence of a main-queue gap between two named kernels (rocprofv3 rocpd database):
+python scripts/rocpd_window.py DB "prev kernel substring" "next kernel substring" [occurrence] [margin_us]"""
+import re, sqlite3, sys
 
 
 def short(n):
@@ -10,27 +8,22 @@ def short(n):
     return n[:70]
 
 
-def main(path):
-    c = sqlite3.connect(path)
-    rows = c.execute("select name, start, end, queue_id from kernels order by start").fetchall()
-    ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
-    a, b = ad[-2], ad[-1]
-    step = rows[a:b + 1]
-    t0 = step[0][1]
-    # head: from the last attn_fwd to the first attn_bwd
-    i0 = max(i for i, r in enumerate(step) if "attn_fwd_kernel" in r[0])
-    i1 = min(i for i, r in enumerate(step) if "attn_bwd" in r[0])
-    print(f"== head section: {1e-3 * (step[i1][1] - step[i0][1]):.1f} us between the last attention forward and the first attention backward")
-    for n, s, e, q in step[i0:i1 + 1]:
-        print(f"  q{q} +{1e-3 * (s - step[i0][1]):8.1f} us  {1e-3 * (e - s):7.1f} us  {short(n)}")
-    print("== step boundary (optimizer .. first attention forward)")
-    j1 = min(i for i, r in enumerate(step) if "attn_fwd_kernel" in r[0])
-    for n, s, e, q in step[:j1 + 1]:
-        print(f"  q{q} +{1e-3 * (s - t0):8.1f} us  {1e-3 * (e - s):7.1f} us  {short(n)}")
-    print("== end of backward (last 14 kernels before the optimizer)")
-    for n, s, e, q in step[-14:]:
-        print(f"  q{q} {1e-3 * (s - step[-1][1]):9.1f} us  {1e-3 * (e - s):7.1f} us  {short(n)}")
-
-
-if __name__ == "__main__":
-    main(sys.argv[1])
+db, a, b = sys.argv[1:4]
+occ = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+margin = float(sys.argv[5]) * 1e3 if len(sys.argv) > 5 else 60e3
+c = sqlite3.connect(db)
+rows = c.execute("select name, start, end, queue_id from kernels order by start").fetchall()
+ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
+step = rows[ad[-2] + 1:ad[-1] + 1]
+busy = {}
+for r in step:
+    busy[r[3]] = busy.get(r[3], 0) + r[2] - r[1]
+mainq = max(busy, key=busy.get)
+mq = [r for r in step if r[3] == mainq]
+hits = [(x, y) for x, y in zip(mq, mq[1:]) if a in x[0] and b in y[0]]
+x, y = hits[min(occ, len(hits) - 1)]
+t0 = x[2]
+print(f"gap {1e-3 * (y[1] - x[2]):.1f} us between main-queue kernels; times relative to the end of the first, us")
+for r in step:
+    if r[2] >= x[1] - margin and r[1] <= y[2] + margin:
+        print(f"  q{r[3]} {'MAIN' if r[3] == mainq else 'side'}  {1e-3 * (r[1] - t0):9.1f} .. {1e-3 * (r[2] - t0):9.1f}   {short(r[0])}")
