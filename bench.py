@@ -344,7 +344,7 @@ def main():
     # roofline probe: HIP events around every launch of the dominant kernel (wgrad GEMM) on its launch stream.  Event-record nodes of
     # a captured graph cannot be read back on ROCm 7.2 (hipEventElapsedTime: invalid resource handle), so in --graph mode the probe
     # runs over 3 host-enqueued steps AFTER the timed region.
-    if graphed is None:
+    if graphed is None and os.environ.get("PPF_BENCH_PROBE", "1") != "0":     # (0: A/B of what the probe's event records cost)
         _lib.call("ppf_gemm_probe", 1)
     if world > 1:
         dist.barrier()

@@ -646,7 +646,9 @@ struct Probe {
     std::pair<hipEvent_t, hipEvent_t> acquire() {
         if (used == pool.size()) {
             hipEvent_t a = nullptr, b = nullptr;
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            // timing events that the host only reads after a device synchronise: no system-scope fence at each record
+            const unsigned fl = (getenv("PPF_PROBE_SYSFENCE") && atoi(getenv("PPF_PROBE_SYSFENCE")) != 0) ? 0u : hipEventDisableSystemFence;
+            (void)hipEventCreateWithFlags(&a, fl); (void)hipEventCreateWithFlags(&b, fl);
             pool.emplace_back(a, b);
         }
         return pool[used++];
