@@ -252,7 +252,8 @@ def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
         rowmax, zinv = prob
         ds16, partial = ops.th_bwd(qkv, dao, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, rowmax, zinv, B, H, N, D)
         wgrad_lane(store).submit(lambda: ops.th_param_reduce(partial, B, H, N, gv(blk.attn.proj_w.weight), gv(blk.attn.proj_w.bias), gv(blk.attn.proj_l.bias),
-                                                             gv(blk.attn.proj_l.weight)), (partial,))
+                                                             gv(blk.attn.proj_l.weight)), (partial,),
+                                 defer=os.environ.get("PPF_TH_REDUCE_DEFER", "1") != "0")    # launched with the qkv weight gradient: one event record
     else:
         NP = prob.shape[-1]
         # dA_h[q][key] = sum_d dO_h[q][d] V_h[key][d]
