@@ -315,6 +315,14 @@ __global__ void hyper_set_kernel(float* __restrict__ hyper, const HyperVals h) {
     if ((int)threadIdx.x < h.n) hyper[threadIdx.x] = h.v[threadIdx.x];
 }
 
+__global__ __launch_bounds__(256) void copy_2d_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int rows, int w16, long long sp16, long long dp16) {
+    const long long total = (long long)rows * w16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / w16, c = i - r * w16;
+        dst[r * dp16 + c] = src[r * sp16 + c];
+    }
+}
+
 inline int grid_for(int64_t work, int per_block = 256) {
     int64_t g = (work + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -547,6 +555,15 @@ int ppf_transpose_bf16_batched(const void* src, void* dst, const void* desc_i64,
 // own launch path so that a recorded step (engine.ReplayedTrainStep) contains them.
 int ppf_copy_2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width, int64_t rows, hipStream_t stream) {
     PPF_CHECK_ARG(dst && src && width > 0 && rows > 0 && dst_pitch >= width && src_pitch >= width, PPF_ERR_ARG, "ppf_copy_2d: bad arguments");
+    if ((((uintptr_t)dst | (uintptr_t)src | (uint64_t)dst_pitch | (uint64_t)src_pitch | (uint64_t)width) & 15) == 0 && rows * (width / 16) < (int64_t)1 << 31) {
+        // 16-byte aligned on every side: a plain kernel of this library instead of the runtime's rectangular blit (same step time on
+        // cait_xxs24, 10 016 vs 10 028 img/s; one launch path for everything a recorded step contains)
+        const int w16 = (int)(width / 16);
+        hipLaunchKernelGGL(copy_2d_kernel, dim3(grid_for(rows * w16)), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, (int)rows, w16,
+                           (long long)(src_pitch / 16), (long long)(dst_pitch / 16));
+        PPF_LAUNCH_CHECK();
+        return 0;
+    }
     hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)width, (size_t)rows, hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) { ppf_set_error("ppf_copy_2d: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
