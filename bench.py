@@ -46,6 +46,39 @@ CONFIGS = {
 }
 
 
+def wgrad_uncontended(cfg, batch, device):
+    """The dominant kernel (weight-gradient GEMM + nothing else on the chip): the four per-block shapes of the configuration, timed with
+    events on an otherwise idle GPU after the timed region.  `roofline.frac` is the CONTENDED in-step figure the contract asks for (the
+    kernel shares the chip with the main stream's chain); this is the same kernel's own speed, reported next to it."""
+    import torch
+    from protopformer_amd import ops
+    from protopformer_amd.backbone import EPI_ATOMIC
+    D, M = cfg["D"], batch * cfg["N"]
+    shapes = [(3 * D, D), (D, D), (4 * D, D), (D, 4 * D)]                     # qkv, proj, fc1, fc2 weights [out, in]
+    g = torch.Generator(device=device).manual_seed(3)
+    tot_ms, tot_fl = 0.0, 0.0
+    for n_out, n_in in shapes:
+        dy = torch.randn(M, n_out, device=device, generator=g).bfloat16()
+        x = torch.randn(M, n_in, device=device, generator=g).bfloat16()
+        gw = torch.zeros(n_out, n_in, device=device)
+        fn = lambda: ops.gemm(dy, x, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot_ms += e0.elapsed_time(e1) / 8
+        tot_fl += 2.0 * M * n_out * n_in
+    return {"avg_launch_ms_incl_reduce": tot_ms / len(shapes), "achieved": tot_fl / 1e12 / (tot_ms / 1e3), "unit": "TFLOP/s",
+            "frac": tot_fl / 1e12 / (tot_ms / 1e3) / PEAK_BF16_TFLOPS,
+            "how": "qkv / proj / fc1 / fc2 weight gradients of one block, 8 back-to-back launches each on an idle GPU after the timed region; "
+                   "includes the ordered split-K reduce launch behind every GEMM"}
+
+
 def executed_gflop_per_img(cfg):
     """FLOPs the kernels really execute: DeiT blocks from the reservation layer on run on the 1+k reserved rows only
     (backbone.deit_blocks_fwd), so their linear parts scale with (1+k)/N and their attention with ((1+k)/N)^2."""
@@ -419,6 +452,10 @@ def main():
             "gflop_per_img": {"algorithmic": cfg["gflop"], "executed": ex},
             "final_loss": float(loss),
         }
+        try:
+            out["roofline"]["uncontended"] = wgrad_uncontended(cfg, batch, device)
+        except Exception as e:                                          # informational leg: never takes the line down
+            out["roofline"]["uncontended"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
         if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.config == "deit_small" and args.batch is None:
             # BASELINE.json configs[1] and configs[4] (per-GPU shape), 20 steps each in a child process of their own AFTER the headline
             # measurement (this process has released its device memory; nothing below changes `value`)
