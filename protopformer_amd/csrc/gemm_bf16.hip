@@ -324,6 +324,165 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM with 256 x 128 (or 128 x 256) tiles and EIGHT waves (round 4).  The 128 x 128 kernel above pulls 0.9 GB per launch
+// out of L2 -- 45 GB per step, the largest L2 consumer -- and that traffic, not its arithmetic, is what it costs the main stream
+// (profiles/r4_wgrad_l2_knockout.txt: half the loads = +3.3 % of the step).  Two 128 x 128 sub-tiles that share one operand tile in LDS
+// read 25 % less; every wave keeps the 64 x 64 accumulator tile (64 VGPRs) of the four-wave kernel, so the footprint per wave is
+// unchanged and the launch has half as many, twice as large workgroups (48 KiB of operand tiles each).  Both operands transposed
+// (contraction = rows in memory), register-staged with one tile of prefetch, ordered split-K partial tiles (EPI_PARTIAL) only.
+template <int ROWS, int NTHR>
+struct TileT {
+    static constexpr int CPR = ROWS / 8;             // 16-byte chunks per contraction row
+    static constexpr int KPP = NTHR / CPR;           // contraction rows per pass
+    static constexpr int NLD = BK / KPP;             // passes = 16-byte loads per thread
+    static __device__ __forceinline__ unsigned gload(u32x4 (&reg)[NLD], const bf16_t* __restrict__ X, int ld, int R, int row0, int k0, int kend, int tid) {
+        const int c16 = tid % CPR, kb = tid / CPR;
+        const int col = row0 + c16 * 8;
+        const bool cok = (col + 8) <= R;
+        const int cc = cok ? col : 0;
+        unsigned mask = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int kc = k0 + kb + KPP * i;
+            reg[i] = *reinterpret_cast<const u32x4*>(X + (size_t)min(kc, kend - 1) * ld + cc);
+            mask |= (cok && kc < kend) ? (1u << i) : 0u;
+        }
+        return mask;
+    }
+    static __device__ __forceinline__ void sstore(const u32x4 (&reg)[NLD], unsigned mask, unsigned char* tile, int tid) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        const int c16 = tid % CPR, kb = tid / CPR;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            *reinterpret_cast<u32x4*>(tile + lds_off_mode1<ROWS>(kb + KPP * i, c16 * 8)) = ((mask >> i) & 1u) ? reg[i] : zero;
+    }
+    static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int rbase, int ks, int lane) { return TileIO<true, ROWS>::frag(tile, rbase, ks, lane); }
+};
+
+template <int WMW, int WNW, bool COLSUM>
+__global__ __launch_bounds__(64 * WMW * WNW, 1) void wgrad8_kernel(const GemmParams p_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NTHR = 64 * WMW * WNW, TBM = 64 * WMW, TBN = 64 * WNW;
+    using IOA = TileT<TBM, NTHR>;
+    using IOB = TileT<TBN, NTHR>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave % WMW) * 64, wn = (wave / WMW) * 64;
+    const int tiles_n = (p_.N + TBN - 1) / TBN;
+    const int tiles = tiles_n * ((p_.M + TBM - 1) / TBM);
+    const int vid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int zslice = vid_all / tiles, vid = vid_all - zslice * tiles;
+    const int m0 = (vid / tiles_n) * TBM, n0 = (vid % tiles_n) * TBN;
+    GemmParams p = p_;
+    p.zslice = zslice;
+    const int nsplit = p.nsplit;
+    const int kchunk = (((p.K + nsplit - 1) / nsplit) + BK - 1) / BK * BK;
+    const int kbeg = zslice * kchunk;
+    const int kend = min(p.K, kbeg + kchunk);
+    if (kbeg >= kend) return;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    u32x4 ra[IOA::NLD], rb[IOB::NLD];
+    unsigned ma, mb;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 accs[2];
+    if constexpr (COLSUM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[j][r] = 0.f;
+    }
+    const bool do_colsum = COLSUM && p.colsum != nullptr && n0 == 0 && wn == 0;
+    unsigned char* tA = smem;
+    unsigned char* tB = smem + TBM * BK * 2;
+    ma = IOA::gload(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
+    mb = IOB::gload(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
+    IOA::sstore(ra, ma, tA, tid);
+    IOB::sstore(rb, mb, tB, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        {                                                    // next tile into registers while this one is multiplied (past the end: a
+            const int k0 = kbeg + min(kt + 1, nk - 1) * BK;  // harmless re-read of the last tile, never stored)
+            ma = IOA::gload(ra, p.A, p.lda, p.M, m0, k0, kend, tid);
+            mb = IOB::gload(rb, p.B, p.ldb, p.N, n0, k0, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = IOA::frag(tA, wm + 32 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb[i] = IOB::frag(tB, wn + 32 * i, ks, lane);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+            if constexpr (COLSUM) {
+                if (do_colsum) {
+                    bf16x8 ones;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) accs[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[mi], accs[mi], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            IOA::sstore(ra, ma, tA, tid);
+            IOB::sstore(rb, mb, tB, tid);
+        }
+        __syncthreads();
+    }
+    // epilogue: as gemm_kernel (a private 32 x 64 fp32 strip per wave, row-contiguous partial-tile stores)
+    const int h = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * STAGE_LD);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stage + (lane & 31) * STAGE_LD + 32 * ni + 8 * g + 4 * h) =
+                    make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
+        __builtin_amdgcn_wave_barrier();
+        epilogue_rows<EPI_PARTIAL>(p, stage, m0 + wm + 32 * mi, n0 + wn, lane);
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (COLSUM) {
+            const int m = m0 + wm + 32 * mi + (lane & 31);
+            if (do_colsum && h == 0 && m < p.M) {
+                float* dst = p.ws + p.zslice * ((size_t)p.M * p.N + (size_t)p.cs_parts * p.M) + (size_t)p.M * p.N + m;
+                *dst = accs[mi][0];
+            }
+        }
+    }
+}
+
+template <int WMW, int WNW>
+int launch_wgrad8(const GemmParams& p, int splitk, hipStream_t stream) {
+    auto kern = wgrad8_kernel<WMW, WNW, true>;
+    constexpr int NTHR = 64 * WMW * WNW, TBM = 64 * WMW, TBN = 64 * WNW;
+    constexpr int opnd = (TBM + TBN) * BK * 2, strips = (NTHR / 64) * 32 * STAGE_LD * 4;
+    constexpr int lds = opnd > strips ? opnd : strips;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(wgrad8): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+    hipLaunchKernelGGL(kern, dim3(tiles * splitk), dim3(NTHR), lds, stream, p);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // 128x128x64 tiles, both operands contraction-contiguous, FOUR workgroups per CU.  The K=384 GEMMs of this model are bound by
 // the length of each workgroup's dependent chain (load round trip -> LDS -> MFMA -> epilogue), i.e. by how many independent
 // workgroups a CU interleaves.  Loading with global_load_lds_dwordx4 removes the 32 staging registers (<= 128 VGPRs: four
@@ -766,7 +925,16 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                 p.nsplit = ns;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (g_probe.on) { auto ev = g_probe.acquire(); e0 = ev.first; e1 = ev.second; (void)hipEventRecord(e0, stream); }
-                int rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
+                // eight-wave tiles where one output side is long and the other at least 384: 256 x 128 (rows) or 128 x 256 (columns).
+                // Same-box: deit_small +0.1 .. +0.4 % in four A/Bs with 19.5 % fewer L2 requests from the weight gradients
+                // (profiles/r4_wgrad_l2_knockout.txt); the D = 192 models lose (deit_tiny -2.8 %, cait_xxs24 -0.8 %: a third of their
+                // 128-column tiles is padding).  PPF_WGRAD8=0: 128 x 128 always.
+                static const int w8 = getenv("PPF_WGRAD8") ? atoi(getenv("PPF_WGRAD8")) : 1;
+                const bool wide = (M < N ? M : N) >= 320;
+                int rc;
+                if (w8 && wide && M >= 512 && M >= N && (M % 256 == 0 || M >= 1024)) rc = launch_wgrad8<4, 2>(p, ns, stream);
+                else if (w8 && wide && N >= 512 && (N % 256 == 0 || N >= 1024)) rc = launch_wgrad8<2, 4>(p, ns, stream);
+                else rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
                 if (g_probe.on) {
                     (void)hipEventRecord(e1, stream);
