@@ -188,9 +188,11 @@ def pmc_traffic():
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
-            for kname, v in ks.items():
-                if "gemm_kernel<true, true, 7" in kname:
-                    return v["hbm_bytes_per_launch"], name
+            # the weight gradient is three kernels since round 4 (wgrad8 256x128 / 128x256 + the 128x128 one): launch-weighted mean
+            hit = [v for kname, v in ks.items() if "gemm_kernel<true, true, 7" in kname or "wgrad8_kernel" in kname]
+            if hit:
+                n = sum(v["launches"] for v in hit)
+                return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / max(n, 1), name
         except Exception:
             continue
     return None, None

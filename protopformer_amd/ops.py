@@ -9,7 +9,8 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_SIGMOID_F32, EPI_RESID, EPI_DGELU, EPI_ATOMIC =
 
 
 # the kernel bench.py's roofline probe (ppf_gemm_probe, HIP events inside the C entry point) reports on
-DOMINANT_NAME = "gemm_kernel<TA=1,TB=1,EPI_PARTIAL,COLSUM> (weight-gradient bf16 MFMA GEMM, split over the contraction, ordered partial tiles)"
+DOMINANT_NAME = ("weight-gradient bf16 MFMA GEMM, split over the contraction, ordered partial tiles: wgrad8_kernel<4,2> / <2,4> (256x128 / 128x256 tiles) "
+                 "and gemm_kernel<TA=1,TB=1,EPI_PARTIAL,COLSUM> (128x128)")
 
 
 _WORKSPACE = {}
