@@ -146,3 +146,32 @@ def test_gemm_224_row_tiles_nt(M, N, K):
     b2 = torch.zeros(128, 64, device="cuda"); b2[:, 0] = torch.arange(128, device="cuda") % 5 - 2.0
     o2 = ops.gemm(a2.bfloat16(), b2.bfloat16(), epi=ops.EPI_BF16).float()
     assert torch.equal(o2, (a2[:, :1] @ b2[:, :1].t()))
+
+
+@pytest.mark.parametrize("n_out,n_in,rows", [(1536, 384, 8192), (1152, 384, 4160), (384, 1536, 8192), (1032, 392, 2120), (400, 1288, 1992), (768, 384, 4096)])
+def test_gemm_wgrad_eight_wave_tiles(n_out, n_in, rows):
+    """wgrad8_kernel (256 x 128 / 128 x 256 tiles, eight waves): dW += dy^T x with the ordered split-K reduce against an fp32 reference, ragged
+    edge tiles on either side and in the contraction, bias-gradient column sums, accumulation into a non-zero C, bit-identical repeats."""
+    from protopformer_amd import ops
+    dy = _mk((rows, n_out), 0.5, 3).bfloat16(); x = _mk((rows, n_in), 0.5, 4).bfloat16()
+    base = _mk((n_out, n_in), 1.0, 5)
+    ref = base.double() + dy.double().t() @ x.double()
+    ref_cs = dy.double().sum(0)
+
+    def run():
+        gw = base.clone(); gb = torch.zeros(n_out, device="cuda")
+        ops.gemm(dy, x, trans_a=True, trans_b=True, epi=ops.EPI_ATOMIC, out=gw, colsum=gb)
+        return gw, gb
+
+    gw, gb = run()
+    assert_close(gw, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max()), what="dW (eight-wave tiles)")
+    assert_close(gb, ref_cs, rtol=2e-3, atol=2e-4 * float(ref_cs.abs().max()), what="column sums of dy")
+    for _ in range(3):
+        g2, b2 = run()
+        assert torch.equal(g2, gw) and torch.equal(b2, gb)
+    # transpose-detecting pattern: dW[i][j] = i-pattern * j-pattern from a single contraction row
+    d2 = torch.zeros(rows, n_out, device="cuda"); d2[7] = torch.arange(n_out, device="cuda") % 13 - 6.0
+    x2 = torch.zeros(rows, n_in, device="cuda"); x2[7] = torch.arange(n_in, device="cuda") % 7 - 3.0
+    o2 = torch.zeros(n_out, n_in, device="cuda")
+    ops.gemm(d2.bfloat16(), x2.bfloat16(), trans_a=True, trans_b=True, epi=ops.EPI_ATOMIC, out=o2)
+    assert torch.equal(o2, d2[7][:, None] * x2[7][None, :])
