@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 7
+#define PPF_ABI_VERSION 8
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -197,6 +197,15 @@ int ppf_rollout_threshold(const float* hm_layer, int B, int N, int NP, int kdrop
 int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int NP, const float* init_rows, int n_init, int lead,
                 int kdrop, int kdrop_init, float identity, int k, const void* thr_u32, float* cls_attn, int* idx, float* policy,
                 ppf_stream_t stream);
+/* The rollout split for a two-stream schedule (round 4): everything of a layer's step that does not depend on the chain -- the order
+ * statistic, the discard, the row sums -- is done per layer as soon as its head-mean map exists, leaving a column-compressed record of
+ * the kept entries per sample (ppf_rollout_compact_bytes(N, kdrop) bytes; 0 = form not applicable: use ppf_rollout); the chain at the
+ * reservation layer then reads ~22 KB instead of the 157 KB map per layer and sample.  Same outputs as ppf_rollout up to the summation
+ * order inside a column (deit_models_attn.py:99-124, 223-234; cait_models_attn.py:223-261). */
+size_t ppf_rollout_compact_bytes(int N, int kdrop);
+int ppf_rollout_compact_layer(const float* hm_layer, int B, int N, int NP, int kdrop, float identity, void* recs_layer, ppf_stream_t stream);
+int ppf_rollout_compact(const void* recs, int L, int B, int N, const float* init_rows, int n_init, int lead, int kdrop, int kdrop_init,
+                        float identity, int k, float* cls_attn, int* idx, float* policy, ppf_stream_t stream);
 /* topk(k) + ascending sort of indices on given scores [B][n] (protopformer.py:157-158, 273-274) */
 int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, ppf_stream_t stream);
 

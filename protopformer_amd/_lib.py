@@ -34,6 +34,8 @@ SIGS = {
     "ppf_attn_bwd": "pppppppp" "iiiii" "i" "s",
     "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "pppp" "s",
     "ppf_rollout_threshold": "p" "iiii" "p" "s",
+    "ppf_rollout_compact_layer": "p" "iiii" "f" "p" "s",
+    "ppf_rollout_compact": "p" "iii" "p" "iiii" "f" "i" "ppp" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",
     "ppf_proto_bwd_rows": "pliip" "iiii" "f" "ppp" "i" "ppp" "l" "p" "pz" "s",
@@ -81,7 +83,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 7               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 8               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
@@ -109,6 +111,8 @@ def lib():
         _lib.ppf_sgemm_pair_workspace.argtypes = [ctypes.c_int] * 5
         _lib.ppf_proto_bwd_single_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_bwd_single_workspace.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_rollout_compact_bytes.restype = ctypes.c_size_t
+        _lib.ppf_rollout_compact_bytes.argtypes = [ctypes.c_int] * 2
         _lib.ppf_proto_bwd_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_bwd_workspace.argtypes = [ctypes.c_int] * 6
         _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int

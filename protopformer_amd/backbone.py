@@ -90,6 +90,12 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
     thr = torch.empty((max(reserve_layer, 1), B), dtype=torch.int32, device=x.device)       # rollout discard thresholds per (layer, sample)
     side_thr = reserve_layer > 0 and os.environ.get("PPF_ROLLOUT_SIDE", "1") != "0"
+    # PPF_ROLLOUT_COMPACT=1 (round 4, opt-in): the side stream leaves each layer's processed map in column-compressed form (order statistic,
+    # discard, row sums done) and the chain at the reservation layer reads 22 KB instead of 157 KB per layer and sample: the main stream's
+    # wait for the chain shrinks from 168 to 33 us, but the heavier per-layer kernel (130 vs 71 us under the forward pass) costs the main
+    # stream more than that: deit_small 16 842 -> 16 580, cait_xxs24 10 098 -> 10 021, deit_tiny 26 641 -> 26 822 (profiles/r4_queue_gaps.txt)
+    rec_bytes = ops.rollout_compact_bytes(N) if (side_thr and os.environ.get("PPF_ROLLOUT_COMPACT", "0") != "0") else 0
+    recs = torch.empty((max(reserve_layer, 1), B, rec_bytes), dtype=torch.uint8, device=x.device) if rec_bytes else None
     if compact is None:
         compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
     policy = None
@@ -108,7 +114,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
             if rolled is not None:
                 cls_attn, idx, policy = rolled
             else:
-                cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None)
+                cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, compact=recs)
             if compact:
                 rows = ops.reserved_rows_map(idx, N)
                 x = ops.gather_rows(x, rows)
@@ -130,15 +136,18 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
             def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i, hm_fused=hm_fused):
                 if "headmean" not in _KO and not hm_fused:
                     ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
-                if side_thr and "thr" not in _KO:
+                if recs is not None:
+                    ops.rollout_compact_layer(hm[i], recs[i], N)   # the r-independent part of this layer's rollout step, off the critical path
+                elif side_thr and "thr" not in _KO:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
             # (PPF_ROLLOUT_BATCH = n: the side launches of n consecutive layers go out under one main-stream event record)
-            lane.submit(side, (qkv, rowmax, zinv, hm, thr), defer=(i % _ROLL_BATCH != _ROLL_BATCH - 1) and i != reserve_layer - 1)
+            # ... except in front of the reservation: the chain needs the last layers' thresholds first, and the main stream waits for it
+            lane.submit(side, (qkv, rowmax, zinv, hm, thr) + ((recs,) if recs is not None else ()), defer=(i % _ROLL_BATCH != _ROLL_BATCH - 1) and i < reserve_layer - _ROLL_TAIL)
             if roll_side and i == reserve_layer - 1:
                 # the rollout chain (176 us, one workgroup per sample) depends only on the head-mean maps and thresholds the lane has
                 # produced: it runs there, right behind the last map, under the rest of this block instead of in front of the next one
                 rolled = ops.rollout_outputs(B, N, reserve_k, 1, x.device)
-                lane.submit(lambda: ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, out=rolled),
+                lane.submit(lambda: ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, out=rolled, compact=recs),
                             (hm, thr) + rolled)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         if fused:
@@ -290,6 +299,7 @@ def wgrad_lane(store):
 # models (embed dim <= 256: deit_tiny +1.8 % same-box, cait_xxs24 +-0), whose kernels are short against the packet boundaries; at
 # D = 384 the later start of the parked GEMM costs more than the records (-0.5 %).  PPF_WGRAD_DEFER=0 / 1: never / always.
 _WGRAD_DEFER = os.environ.get("PPF_WGRAD_DEFER", "auto")
+_ROLL_TAIL = max(1, int(os.environ.get("PPF_ROLLOUT_TAIL", "1")))        # layers in front of the reservation whose side launches are never parked
 _ROLL_BATCH = max(1, int(os.environ.get("PPF_ROLLOUT_BATCH", "3")))      # 3: +0.9 % deit_tiny, +0.6 % deit_small same-box against 1
 
 

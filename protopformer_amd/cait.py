@@ -140,6 +140,9 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     depth = len(feats.blocks)
     hm = torch.empty((depth, B, N, NP), dtype=torch.float32, device=x.device)
     thr = torch.empty((depth, B), dtype=torch.int32, device=x.device)          # rollout discard thresholds per (layer, sample)
+    # PPF_ROLLOUT_COMPACT=1: column-compressed records of the processed maps instead (opt-in, see backbone.forward_blocks)
+    rec_bytes = ops.rollout_compact_bytes(N) if os.environ.get("PPF_ROLLOUT_COMPACT", "0") != "0" else 0
+    recs = torch.empty((depth, B, rec_bytes), dtype=torch.uint8, device=x.device) if rec_bytes else None
     lane = wgrad_lane(store)
     layers = []
     x = x.reshape(M, D)
@@ -155,7 +158,8 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, prob, a16 = _th_attention_fwd(blk, qkv, B, H, N, D, hm[i])
         # the rollout's order statistic, off the critical path (three layers per main-stream event record, as backbone.forward_blocks)
-        lane.submit(lambda i=i: ops.rollout_threshold(hm[i], thr[i], N), (hm, thr), defer=(i % rb != rb - 1) and i != len(feats.blocks) - 1)
+        side = (lambda i=i: ops.rollout_compact_layer(hm[i], recs[i], N)) if recs is not None else (lambda i=i: ops.rollout_threshold(hm[i], thr[i], N))
+        lane.submit(side, (hm, thr) + ((recs,) if recs is not None else ()), defer=(i % rb != rb - 1) and i != len(feats.blocks) - 1)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         if rowk:
@@ -194,7 +198,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         if j == reserve_layer:
             init_rows = rowmeans[:j]                                              # class-attention rows produced so far (cait:249-251)
             lane.join()
-            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows, thr=thr)
+            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows, thr=thr, compact=recs)
         u = ops.cat_rows(cls, xt).reshape(B * N1, D)
         n, mean1, rstd1 = ops.layernorm_fwd(u, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         kk = ops.gemm(n, store.w16(blk.attn.k.weight), epi=EPI_BF16, bias=blk.attn.k.bias)

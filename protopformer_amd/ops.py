@@ -286,6 +286,18 @@ def rollout_threshold(hm_layer, thr_out, N, discard_ratio=0.9):
     _lib.call("ppf_rollout_threshold", hm_layer, B, N, NP, int(N * N * discard_ratio), thr_out)
 
 
+def rollout_compact_bytes(N, discard_ratio=0.9):
+    """Bytes of one (layer, sample) record of rollout_compact_layer, or 0 when the column-compressed form does not apply."""
+    return int(_lib.lib().ppf_rollout_compact_bytes(N, int(N * N * discard_ratio)))
+
+
+def rollout_compact_layer(hm_layer, recs_layer, N, discard_ratio=0.9, identity=0.2):
+    """recs_layer [B, rollout_compact_bytes(N)] uint8 <- the layer's processed map (discard, +identity, normalisation, row sums) in
+    column-compressed form: everything of the rollout step that does not depend on the chain (side stream, behind the layer's map)."""
+    B, _, NP = hm_layer.shape
+    _lib.call("ppf_rollout_compact_layer", hm_layer, B, N, NP, int(N * N * discard_ratio), float(identity), recs_layer)
+
+
 def rollout_outputs(B, N, k, lead, device):
     """(cls_attn [B,N-lead], idx int32 [B,k], policy [B,N-lead+1]) buffers for rollout(out=...)."""
     Nk = N - lead
@@ -293,15 +305,19 @@ def rollout_outputs(B, N, k, lead, device):
             torch.empty((B, Nk + 1), dtype=torch.float32, device=device))
 
 
-def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None, out=None):
+def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None, out=None, compact=None):
     """hm: [L,B,N,NP] fp32 head-mean attention. Returns (cls_attn [B,N-lead], idx int32 [B,k] ascending, policy [B,N-lead+1]);
-    out = rollout_outputs(...) to write into existing buffers (no allocation: usable on the side-stream lane)."""
+    out = rollout_outputs(...) to write into existing buffers (no allocation: usable on the side-stream lane).
+    compact = [L,B,rollout_compact_bytes(N)] records of rollout_compact_layer: the chain reads those instead of hm / thr."""
     _chk(hm, torch.float32)
     NP = hm.shape[-1]
     cls_attn, idx, policy = out if out is not None else rollout_outputs(B, N, k, lead, hm.device)
     n_init = init_rows.shape[0] if init_rows is not None else 0
     # discard counts in double precision, exactly like the reference's int(numel * ratio)
     kdrop, kdrop_init = int(N * N * discard_ratio), int((N + 1) * discard_ratio)
+    if compact is not None:
+        _lib.call("ppf_rollout_compact", compact, L, B, N, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, cls_attn, idx, policy)
+        return cls_attn, idx, policy
     _lib.call("ppf_rollout", hm, B * N * NP, L, B, N, NP, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, thr, cls_attn, idx, policy)
     return cls_attn, idx, policy
 
