@@ -402,15 +402,19 @@ __global__ __launch_bounds__(NTHR) void rollout_threshold_kernel(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const float* f = f_layer + (size_t)b * N * NP;
+    // the order statistic does not care which thread holds which element: one 16-byte load per (row, lane) -- four consecutive columns,
+    // NP is a multiple of 4 and the map 16-byte aligned -- instead of four 4-byte loads (the chain kernel needs the column = lane layout)
     float v[RPW * CPL];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int row = wave + NWAVE * i;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int col = lane + 64 * c;
-            v[i * CPL + c] = (row < N && col < N) ? f[(size_t)row * NP + col] : INFINITY;
-        }
+        const int col = lane * 4;
+        float4 q = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+        if (row < N && col < NP) q = *reinterpret_cast<const float4*>(f + (size_t)row * NP + col);
+        v[i * CPL + 0] = (row < N && col + 0 < N) ? q.x : INFINITY;
+        v[i * CPL + 1] = (row < N && col + 1 < N) ? q.y : INFINITY;
+        v[i * CPL + 2] = (row < N && col + 2 < N) ? q.z : INFINITY;
+        v[i * CPL + 3] = (row < N && col + 3 < N) ? q.w : INFINITY;
     }
     const uint32_t thr = kdrop > 0 ? radix_select<RPW * CPL>(v, kdrop, hist, misc) : 0u;
     if (tid == 0) thr_out[b] = thr;
@@ -453,6 +457,8 @@ int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, hipStrea
 // init_rows: null (DeiT, lead=1) or [n_init][B][N+1] head-mean class-attention rows (CaiT, lead=0).
 // Outputs: cls_attn [B][N-lead], idx [B][k] int32 ascending, policy [B][N-lead+1] float {0,1}.
 int ppf_rollout_threshold(const float* hm_layer, int B, int N, int NP, int kdrop, void* thr_out_u32, hipStream_t stream) {
+    PPF_CHECK_ARG(NP % 4 == 0 && NP <= 64 * CPL && ((uintptr_t)hm_layer & 15) == 0, PPF_ERR_ALIGN,
+                  "ppf_rollout_threshold: the map's row pitch NP=%d must be a multiple of 4 (<= 256) and the map 16-byte aligned", NP);
     PPF_CHECK_ARG(B >= 1 && N >= 2 && N <= 16 * RPW && N <= 64 * CPL - 1 && NP >= N && kdrop >= 0 && kdrop < N * N && hm_layer && thr_out_u32, PPF_ERR_SHAPE,
                   "ppf_rollout_threshold: bad arguments B=%d N=%d NP=%d kdrop=%d", B, N, NP, kdrop);
     hipLaunchKernelGGL(rollout_threshold_kernel, dim3(B), dim3(NTHR), 0, stream, hm_layer, N, NP, kdrop, (uint32_t*)thr_out_u32);
