@@ -298,6 +298,29 @@ def dry_run(args, world, rank):
     return 0 if ok else 1
 
 
+PEAK_HBM_TBPS = 8.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (6.3 TB/s measured achievable)
+
+
+def named_path_report(_lib, steps):
+    """roofline.named_path: the kernels BASELINE.json's north_star names, timed inside real train steps by the library's path probe
+    (HIP events on the launch stream around each launch; csrc/ppf_runtime.hip).  Algorithmic flops / bytes as DESIGN.md section 4 states them."""
+    import ctypes
+    out = {"how": f"HIP events around every launch in {steps} train steps after the timed region (contended in-step time); "
+                  "flops / bytes are algorithmic (DESIGN.md section 4)", "peak_mfma_tflops": PEAK_BF16_TFLOPS, "peak_hbm_tbps": PEAK_HBM_TBPS}
+    for tag, name in ((0, "attention_fwd"), (1, "attention_bwd"), (2, "prototype_fwd")):
+        c_ms, c_n, c_fl, c_by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.call("ppf_path_probe_read", tag, ctypes.addressof(c_ms), ctypes.addressof(c_n), ctypes.addressof(c_fl), ctypes.addressof(c_by))
+        ms, n = c_ms.value, int(c_n.value)
+        if n == 0 or ms <= 0:
+            out[name] = {"launches": 0}
+            continue
+        tf, tb = c_fl.value / 1e12 / (ms / 1e3), c_by.value / 1e12 / (ms / 1e3)
+        out[name] = {"launches_per_step": n / steps, "avg_launch_us": 1e3 * ms / n, "ms_per_step": ms / steps,
+                     "gflop_per_launch": c_fl.value / n / 1e9, "mbytes_per_launch": c_by.value / n / 1e6,
+                     "tflops": tf, "mfma_frac": tf / PEAK_BF16_TFLOPS, "hbm_tbps": tb, "hbm_frac": tb / PEAK_HBM_TBPS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -417,6 +440,19 @@ def main():
         torch.cuda.synchronize()
         _lib.call("ppf_gemm_probe", 0)
         probe_note = "HIP events around every launch of 3 host-enqueued steps after the timed region (graph nodes cannot be timed)"
+    # the kernels the north star names (attention forward / backward, prototype forward): in-step HIP-event time over 3 more steps of
+    # the same kind AFTER the timed region (the ~50 extra event records per step must not touch `value`)
+    named = None
+    if rank == 0 and os.environ.get("PPF_BENCH_PROBE", "1") != "0":
+        try:
+            _lib.call("ppf_path_probe", 1)
+            for _ in range(3):
+                step() if graphed is None else train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
+            torch.cuda.synchronize()
+            _lib.call("ppf_path_probe", 0)
+            named = named_path_report(_lib, 3)
+        except Exception as e:                                          # informational leg: never takes the line down
+            named = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -458,6 +494,8 @@ def main():
             "gflop_per_img": {"algorithmic": cfg["gflop"], "executed": ex},
             "final_loss": float(loss),
         }
+        if named is not None:
+            out["roofline"]["named_path"] = named
         if world == 1 and not args.no_cpu_baseline:
             # the dominant kernel alone on the chip, in a CHILD process after the timed region (its launches must not show up in a
             # kernel trace / counter pass of this process: profiles/ hold the in-step averages)

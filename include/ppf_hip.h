@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 8
+#define PPF_ABI_VERSION 9
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -52,7 +52,7 @@ int ppf_stream_wait_mark(ppf_stream_t stream, int64_t ticket);
  *   dgrad    dx = dy W                    (0,1)  autograd of the above
  *   wgrad    dW += dy^T x (+ db)          (1,1)  split over kc, fp32 atomics into C, colsum[m] += sum_kc A(m,kc)
  * epi: 0 bf16 out | 1 f32 out | 2 bias+GELU(erf): C=gelu(pre) bf16, aux_out=gelu'(pre) as ONE BYTE per element (saved for backward:
- *        code q = rint((d + 0.13) * 255 / 1.26), |error| <= 2.5e-3) | 3 sigmoid f32 out |
+ *        code q = rint(196 d + 26), d' = (q - 26) / 196: 0 and 1 are code points, |error| <= 2.55e-3) | 3 sigmoid f32 out |
  *      4 residual: C f32 = res + rowscale[m/rows_per_group]*colscale[n]*(acc+bias)  (DropPath deit:79-80, LayerScale
  *        cait:156-157), optional aux_out = raw branch output bf16 | 5 dGELU: C bf16 = acc * aux_in (aux_in = the gelu' codes of epi 2) | 6 atomic f32.
  * ldaux counts ELEMENTS of the aux tensor (bytes for epi 2 / 5, bf16 for epi 4). */
@@ -72,6 +72,13 @@ size_t ppf_gemm_workspace_bytes(int M, int N, int K);
  * become event-record nodes: a read after replays returns the last replay's durations. */
 int ppf_gemm_probe(int enable);
 int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, double* bytes);
+
+/* Path probe (round 5): the same mechanism around the kernels BASELINE.json's north_star names -- tag 0 attention forward
+ * (ppf_attn_fwd / ppf_attn_fwd_hm), 1 attention backward (ppf_attn_bwd), 2 prototype forward (ppf_proto_fwd) -- for bench.py's
+ * roofline.named_path.  ppf_path_probe(1) clears and starts, (0) stops, (2) stops and destroys the pools; ppf_path_probe_read
+ * returns the summed in-step kernel time, the launch count and the algorithmic flops / bytes of the recorded launches. */
+int ppf_path_probe(int enable);
+int ppf_path_probe_read(int tag, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* nbatch = batch_outer*batch_inner plain GEMMs; problem (o,i) uses A + o*sa_o + i*sa_i (elements), same for B / C.
  * kpad = 1: contraction-contiguous operands may read the (zero) padding up to the next multiple of 8 beyond K.

@@ -20,6 +20,8 @@ SIGS = {
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",
     "ppf_gemm_probe_read": "pppp",
+    "ppf_path_probe": "i",
+    "ppf_path_probe_read": "ipppp",
     "ppf_layernorm_fwd": "ppppppp" "iif" "s",
     "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "pz" "s",
     "ppf_layernorm_bwd_reduce": "p" "ii" "pppp" "s",
@@ -83,7 +85,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 8               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 9               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None
@@ -247,19 +249,6 @@ def stream_mark(raw):
         _rec.cmds.append((Recorder.MARK, raw, _rec.nslots))
         _rec.nslots += 1
     return t
-
-
-class unrecorded:
-    """Context: library calls made inside run now but stay out of the command list (one-time set-up such as workspace fills)."""
-
-    def __enter__(self):
-        if _rec is not None:
-            _rec.suspended += 1
-
-    def __exit__(self, *exc):
-        if _rec is not None:
-            _rec.suspended -= 1
-        return False
 
 
 def run_live(fn):

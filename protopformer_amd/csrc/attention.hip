@@ -984,6 +984,8 @@ int ppf_attn_fwd(const void* qkv, void* out, const float* policy, float* rowmax,
     int rc = fill(p, qkv, B, H, N, D, policy, rowmax, zinv, self_keep, eps_n, "ppf_attn_fwd");
     if (rc) return rc;
     p.out = (bf16_t*)out;
+    // algorithmic work: QK^T and PV, 2 N^2 hd flops each per (sample, head); qkv in, out + the two statistics out
+    PpfProbeScope probe(PPF_PROBE_ATTN_FWD, stream, 4.0 * B * H * (double)N * N * (D / H), 8.0 * B * N * (double)D + 8.0 * B * H * N);
     return dispatch(D / H, N, "ppf_attn_fwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         hipLaunchKernelGGL((attn_fwd_kernel<decltype(hd)::value, decltype(nt)::value>), dim3((N + G::NW * 32 - 1) / (G::NW * 32), H, B), dim3(G::NTHR), 0, stream, p);
@@ -1003,6 +1005,8 @@ int ppf_attn_fwd_hm(const void* qkv, void* out, const float* policy, float* rowm
     PPF_CHECK_ARG(ppf_attn_fwd_hm_supported(H, N, D), PPF_ERR_SHAPE, "ppf_attn_fwd_hm: head_dim must be 64 and N <= 208 (H=%d N=%d D=%d)", H, N, D);
     PPF_CHECK_ARG(headmean == nullptr || (NP >= N && NP % 4 == 0 && NP < N + 4), PPF_ERR_SHAPE, "ppf_attn_fwd_hm: NP=%d must be N rounded up to a multiple of 4", NP);
     p.out = (bf16_t*)out; p.headmean = headmean; p.NP = NP;
+    PpfProbeScope probe(PPF_PROBE_ATTN_FWD, stream, 4.0 * B * H * (double)N * N * (D / H),
+                        8.0 * B * N * (double)D + 8.0 * B * H * N + (headmean ? 4.0 * B * N * (double)NP : 0.0));
     const int nb = (N + 15) / 16;
     const dim3 grid((nb + F16_WAVES - 1) / F16_WAVES, B);
     constexpr int lds6 = Fwd16<64, 6>::LDS, lds13 = Fwd16<64, 13>::LDS;
@@ -1052,6 +1056,8 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
     static const int mode = getenv("PPF_ATTN_BWD_STREAM") ? atoi(getenv("PPF_ATTN_BWD_STREAM")) : 1;      // 0: the non-persistent one-pass kernel (A/B)
+    // five products of 2 N^2 hd flops per (sample, head): S, dV, dP, dQ, dK; qkv + out + dout in, dqkv out
+    PpfProbeScope probe(PPF_PROBE_ATTN_BWD, stream, 10.0 * B * H * (double)N * N * (D / H), 16.0 * B * N * (double)D + 8.0 * B * H * N);
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;

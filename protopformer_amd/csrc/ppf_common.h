@@ -34,6 +34,18 @@ extern "C" void ppf_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// Path probe (bench.py's roofline.named_path, ppf_runtime.hip): HIP events from a reused pool around the launches of one of the kernels
+// the north star names, on the launch stream; off (two loads and a branch) unless ppf_path_probe(1) switched it on.
+enum { PPF_PROBE_ATTN_FWD = 0, PPF_PROBE_ATTN_BWD = 1, PPF_PROBE_PROTO_FWD = 2, PPF_PROBE_NTAGS = 3 };
+#ifdef __cplusplus
+struct PpfProbeScope {
+    hipEvent_t stop = nullptr;
+    hipStream_t stream;
+    PpfProbeScope(int tag, hipStream_t stream, double flops, double bytes);   // records the start event when the probe is on
+    ~PpfProbeScope();                                                          // records the stop event
+};
+#endif
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // fp32 -> bf16 (round-to-nearest-even): native conversion, lowers to v_cvt_pk_bf16_f32 on gfx950 (branch-free)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

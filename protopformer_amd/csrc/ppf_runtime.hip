@@ -3,6 +3,9 @@
 #include "ppf_hip.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -74,6 +77,68 @@ int ppf_stream_wait_mark(hipStream_t stream, int64_t ticket) {
     if (ticket < 0 || g_seq - ticket >= RING) return 0;
     hipError_t e = hipStreamWaitEvent(stream, ring_event(ticket), 0);
     if (e != hipSuccess) { ppf_set_error("ppf_stream_wait_mark: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+// ---- path probe: in-step HIP-event time of the kernels the north star names (attention forward / backward, prototype forward) ----
+namespace {
+struct PathProbe {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+    double flops = 0.0, bytes = 0.0;
+};
+PathProbe g_path[PPF_PROBE_NTAGS];
+bool g_path_on = false;
+}  // namespace
+
+}  // extern "C"
+
+PpfProbeScope::PpfProbeScope(int tag, hipStream_t s, double flops, double bytes) : stream(s) {
+    if (!g_path_on || tag < 0 || tag >= PPF_PROBE_NTAGS) return;
+    PathProbe& pr = g_path[tag];
+    if (pr.used == pr.pool.size()) {
+        hipEvent_t a = nullptr, b = nullptr;           // timing events the host reads after a device synchronise: agent scope only
+        (void)hipEventCreateWithFlags(&a, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&b, hipEventDisableSystemFence);
+        pr.pool.emplace_back(a, b);
+    }
+    auto& ev = pr.pool[pr.used++];
+    pr.flops += flops; pr.bytes += bytes;
+    (void)hipEventRecord(ev.first, stream);
+    stop = ev.second;
+}
+PpfProbeScope::~PpfProbeScope() { if (stop) (void)hipEventRecord(stop, stream); }
+
+extern "C" {
+
+// enable = 1 clears the counters and starts recording, 0 stops, 2 stops and destroys the event pools.
+int ppf_path_probe(int enable) {
+    for (auto& pr : g_path) {
+        if (enable == 1) { pr.used = 0; pr.flops = 0.0; pr.bytes = 0.0; }
+        if (enable == 2) {
+            for (auto& e : pr.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+            pr.pool.clear(); pr.used = 0;
+        }
+    }
+    g_path_on = enable == 1;
+    return 0;
+}
+
+// Synchronises tag's events: summed kernel milliseconds, launches, algorithmic flops and bytes since ppf_path_probe(1).
+int ppf_path_probe_read(int tag, double* ms_total, int64_t* launches, double* flops, double* bytes) {
+    PPF_CHECK_ARG(tag >= 0 && tag < PPF_PROBE_NTAGS, PPF_ERR_ARG, "ppf_path_probe_read: tag %d", tag);
+    PathProbe& pr = g_path[tag];
+    double ms = 0.0;
+    for (size_t i = 0; i < pr.used; ++i) {
+        hipError_t rc = hipEventSynchronize(pr.pool[i].second);
+        float t = 0.f;
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&t, pr.pool[i].first, pr.pool[i].second);
+        if (rc != hipSuccess) { ppf_set_error("ppf_path_probe_read: %s", hipGetErrorString(rc)); return (int)rc; }
+        ms += t;
+    }
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = (int64_t)pr.used;
+    if (flops) *flops = pr.flops;
+    if (bytes) *bytes = pr.bytes;
     return 0;
 }
 

@@ -940,6 +940,9 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
     p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
     p.act_max = act_max; p.argmax = argmax; p.dist_full = dist_full; p.act_full = act_full;
     const int gx = (P + PB - 1) / PB;
+    // algorithmic work: the (B T) x Dp . Dp x P contraction; tokens + prototypes in, the maps that are asked for + max / arg-max out
+    PpfProbeScope probe(PPF_PROBE_PROTO_FWD, stream, 2.0 * B * T * (double)Dp * P,
+                        4.0 * ((double)B * T * Dp + (double)P * Dp + (double)B * P * T * ((dist_full ? 1 : 0) + (act_full ? 1 : 0)) + 2.0 * B * P));
     // default: the split-bf16 contraction; PPF_PROTO_FP32=1 (or Dp not a multiple of 16): the fp32-MFMA kernel
     static const int fp32_mfma = getenv("PPF_PROTO_FP32") ? atoi(getenv("PPF_PROTO_FP32")) : 0;
     const bool x6 = !fp32_mfma && Dp % 16 == 0;

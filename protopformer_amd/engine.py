@@ -280,6 +280,7 @@ class GradSync:
         self.cuda = flat_grads.is_cuda
         self.stream = torch.cuda.Stream() if (self.cuda and use_side_stream) else None
         self.pending = []
+        self.guard = None                                     # the loss summed over the ranks (reduce_guard)
         self.launched = 0                                     # collectives issued so far (tests: the forced single-rank path really ran)
 
     def chunk_ready(self, c, also=()):
@@ -308,6 +309,28 @@ class GradSync:
                 if st is not None:
                     torch.cuda.current_stream().wait_stream(st)
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def reduce_guard(self, loss):
+        """The device-side non-finite stop (ppf_adamw_step_guarded) must take the same decision on every rank: returns a copy of the loss
+        scalar that is being summed over the ranks on the communication stream (a NaN / inf on ANY rank makes the sum non-finite, so every
+        rank skips that update -- otherwise the rank with the bad loss would skip while the others apply the all-reduced NaN gradients).
+        Single rank without PPF_FORCE_GRADSYNC: the loss itself.  finish() waits for it with the gradient chunks."""
+        if self.world == 1 and not self.force:
+            return loss.detach().reshape(1)
+        if self.guard is None:                                # one buffer for the life of the object: a recorded step binds its address
+            self.guard = torch.zeros(1, dtype=torch.float32, device=loss.device)
+        g = self.guard
+        g.copy_(loss.detach().reshape(1))
+        self.launched += 1
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        return g
 
     def finish(self):
         """Wait for all chunks; returns the scale (1/world) the optimizer must apply to the summed gradients."""
@@ -379,6 +402,12 @@ def _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_
         print("Loss is {}, stopping training".format(loss.item()))
         sys.exit(1)
     optimizer.zero_grad()
+    guard = loss.detach().reshape(1)
+    if grad_sync is not None:
+        # the guard of the device-side non-finite stop: the loss summed over the ranks (in place, on the communication stream, under backward)
+        box = [guard]
+        _lib.run_live(lambda: box.__setitem__(0, grad_sync.reduce_guard(loss)))
+        guard = box[0]
     model._grad_sync = grad_sync
     loss.backward(gradient=ops.const_scalar(loss.device, 1.0))    # cached seed: no ones_like fill, and the loss Fns skip their scaling
     model._grad_sync = None
@@ -386,7 +415,7 @@ def _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_
         _lib.run_live(lambda: setattr(optimizer, "grad_scale", grad_sync.finish()))
     if max_norm is not None:                                      # loss_scaler(..., clip_grad=max_norm) (engine_proto.py:74-76)
         optimizer.clip_grad_norm(max_norm)
-    return loss, cov, mean
+    return loss, cov, mean, guard
 
 
 def train_one_step(model, criterion, samples, targets, optimizer, epoch=20, ppc_cov_coe=0.1, ppc_mean_coe=0.5, use_ppc_loss=True,
@@ -394,9 +423,9 @@ def train_one_step(model, criterion, samples, targets, optimizer, epoch=20, ppc_
     """One iteration of tools/engine_proto.py:41-81 (without logging). Returns the detached loss tensors.
     The reference's NativeScaler (fp16 loss scaling) has no role here: the kernels accumulate in fp32 from bf16 operands."""
     _unwrap(model)
-    loss, cov, mean = _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss,
-                                        grad_sync, check_finite, max_norm)
-    optimizer.step(loss_guard=loss.detach().reshape(1))
+    loss, cov, mean, guard = _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss,
+                                               grad_sync, check_finite, max_norm)
+    optimizer.step(loss_guard=guard)
     return loss.detach(), (cov.detach() if cov is not None else None), (mean.detach() if mean is not None else None)
 
 
@@ -444,8 +473,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            loss, cov, mean = _forward_backward(self.model, self.criterion, self.static_in[0], self.static_in[1], opt, **self.kw)
-            opt.launch_update(loss.detach().reshape(1))
+            loss, cov, mean, guard = _forward_backward(self.model, self.criterion, self.static_in[0], self.static_in[1], opt, **self.kw)
+            opt.launch_update(guard)
             self.out = (loss.detach(), cov.detach() if cov is not None else None, mean.detach() if mean is not None else None)
 
     def __call__(self, samples, targets):
@@ -552,6 +581,10 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, arg
             logger(f"Epoch: [{epoch}] it {it} loss {v:.4f} lr {optimizer.param_groups[0]['lr']:.6f}")
             total += v
             n += 1
+    # a non-finite loss between the last log read and the end of the epoch must not reach the epoch-end checkpoint / evaluation
+    if int(optimizer.nonfinite) != 0:
+        logger("Loss is non-finite in an earlier step, stopping training")
+        sys.exit(1)
     return {"loss": total / max(n, 1), "lr": optimizer.param_groups[0]["lr"]}
 
 
@@ -577,6 +610,10 @@ def evaluate(data_loader, model, device):
 def save_checkpoint(path, model, optimizer, lr_scheduler, epoch, args=None, master_only=True):
     """The reference's checkpoint dict (main.py:436-447, 460-471; tools/utils.py:242-244 save_on_master):
     {'model', 'optimizer', 'lr_scheduler', 'epoch', 'model_ema', 'args'} -- 'scaler' is omitted (no fp16 loss scaling here)."""
+    flag = getattr(optimizer, "nonfinite", None)
+    if flag is not None and int(flag) != 0:
+        raise RuntimeError("save_checkpoint: the optimizer's non-finite-loss flag is raised (a step was skipped because its loss was NaN / "
+                           "inf, engine_proto.py:66-70 would have stopped there); refusing to write a checkpoint from this state")
     if master_only and dist.is_initialized() and dist.get_rank() != 0:
         return
     ck = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()},

@@ -72,6 +72,8 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
     ldaux = 0
     for t in (aux_in, aux_out):
         if t is not None:
+            # EPI_GELU / EPI_DGELU: gelu' as 8-bit codes, ldaux counts BYTES (ABI >= 6); EPI_RESID: the bf16 unscaled branch
+            _chk(t, torch.uint8 if epi in (EPI_GELU, EPI_DGELU) else torch.bfloat16)
             ldaux = t.shape[-1]
     ws = None
     if epi == EPI_ATOMIC:

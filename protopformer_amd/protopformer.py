@@ -60,21 +60,42 @@ _SIDE_FIRST = os.environ.get("PPF_PROTO_SIDE_FIRST", "1") != "0"
 # tensor that the prototype-layer backward would scan twice, PPCLossFn.backward hands autograd a zero-stride placeholder of that shape
 # and parks the block rows here, keyed by the placeholder's storage; ProtoLayerFn.backward picks them up (ppf_proto_bwd_rows).  Only taken
 # when the activation map comes straight (through views) from ProtoLayerFn; a gradient that autograd had to combine with another one
-# is detected below and reported -- PPF_PROTO_ROWS=0 restores the dense exchange.
+# arrives dense (placeholder zeros + the other gradient) and gets the parked rows added (_rows_for) -- PPF_PROTO_ROWS=0 = always dense.
 _PROTO_ROWS = os.environ.get("PPF_PROTO_ROWS", "1") != "0"
 _PENDING_ROWS = {}
 
 
 def _rows_for(g_full):
-    """(rows, label, ppc) parked for this gradient, or None when it is an ordinary dense tensor."""
+    """(rows, label, ppc), g_full: the block rows parked for this gradient (then g_full is None), or (None, g_full) for an ordinary dense
+    tensor.  When autograd has ADDED the placeholder (zeros) to another consumer's gradient, g_full arrives dense with the rows still
+    parked: they are folded into a copy of it (rare path, plain indexing) so that such a graph gets the right gradient by default."""
     if not _PENDING_ROWS:
-        return None
-    hit = _PENDING_ROWS.pop(g_full.data_ptr(), None) if g_full is not None and not any(g_full.stride()) else None
-    if hit is None:
-        _PENDING_ROWS.clear()
-        raise RuntimeError("protopformer_amd: the block-form PPC gradient did not reach the prototype layer unchanged (the activation map "
-                           "has another consumer in this graph); set PPF_PROTO_ROWS=0 to exchange dense gradients")
-    return hit[1:]
+        return None, g_full
+    if g_full is not None and not any(g_full.stride()):
+        hit = _PENDING_ROWS.pop(g_full.data_ptr(), None)
+        if hit is not None:
+            return hit[1:], None
+    if g_full is not None and len(_PENDING_ROWS) == 1:
+        _, (_, rows, label, ppc) = _PENDING_ROWS.popitem()
+        B, P = g_full.shape[0], g_full.shape[1]
+        g = g_full.reshape(B, P // ppc, ppc, -1).clone()
+        g[torch.arange(B, device=g.device), label] += rows.reshape(B, ppc, -1)
+        return None, g.reshape(g_full.shape)
+    _PENDING_ROWS.clear()
+    raise RuntimeError("protopformer_amd: a block-form PPC gradient is parked but the prototype layer received no activation-map gradient "
+                       "to attach it to; set PPF_PROTO_ROWS=0 to exchange dense gradients")
+
+
+_ZERO_POOL = {}
+
+
+def _zero_holder(device):
+    """One element of a per-device pool of fp32 zeros (never written; rotating, so that two pending gradients get distinct addresses)."""
+    ent = _ZERO_POOL.get(device)
+    if ent is None:
+        ent = _ZERO_POOL[device] = [ops.zeros((64,), torch.float32, device), 0]
+    ent[1] = (ent[1] + 1) % 64
+    return ent[0][ent[1]:ent[1] + 1]
 
 
 def _check_rows_consumed():
@@ -134,9 +155,7 @@ class ProtoLayerFn(torch.autograd.Function):
         df = torch.empty(f.shape, dtype=f.dtype, device=f.device) if full else ops.zeros(f.shape, f.dtype, f.device)
         lane = wgrad_lane(store)      # prototype gradients feed only the optimizer: side stream, under the backbone backward
         torch.autograd.Variable._execution_engine.queue_callback(lane.join)     # ... joined when this backward pass ends
-        rows = _rows_for(g_full)
-        if rows is not None:
-            g_full = None
+        rows, g_full = _rows_for(g_full)
         if g_l is not None or g_full is not None or rows is not None:
             gf = g_full.contiguous() if g_full is not None else None
             gl = g_l.contiguous() if g_l is not None else None
@@ -213,7 +232,7 @@ class PPCLossFn(torch.autograd.Function):
         um = up_mean.reshape(1).float().contiguous() if up_mean is not None else None
         if ctx.block_rows:
             rows = ops.ppc_loss_bwd_rows(gcov, gmean, uc, um)
-            holder = torch.empty(1, dtype=gcov.dtype, device=gcov.device)             # never read: its storage address is the key
+            holder = _zero_holder(gcov.device)        # its storage address is the key; zeros, so that a sum with another gradient stays exact
             _PENDING_ROWS[holder.data_ptr()] = (holder, rows, label, gcov.shape[1])
             torch.autograd.Variable._execution_engine.queue_callback(_check_rows_consumed)
             return holder.expand(ctx.shape), None, None, None, None, None, None

@@ -29,6 +29,14 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def assert_elementwise(a, b, tol, what=""):
+    """The element-wise form of a `rel_err(a, b) < tol` gate: every element within tol * |b| + tol * max|b|.
+    rel_err is max-abs-error over max-abs-reference (one number for the tensor); this states the same bound per element, with the
+    relative term on top, so that a report of `rel_err` can never hide an element that is off by more than tol of the tensor's scale."""
+    b_ = torch.as_tensor(b).detach().double().cpu()
+    assert_close(torch.as_tensor(a).detach(), b_, rtol=tol, atol=tol * float(b_.abs().max()), what=what)
+
+
 def assert_close(a, b, rtol, atol=0.0, what=""):
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
@@ -101,12 +109,12 @@ def report(name, **values):
 
 
 # gelu'(x) as the fc1 epilogue saves it for backward: 8-bit linear codes (csrc/gemm_common.h gelu8_*)
-GELU8_LO, GELU8_STEP = -0.13, 1.26 / 255.0
+GELU8_ZERO, GELU8_STEP = 26.0, 1.0 / 196.0        # 0 -> code 26, 1 -> code 222: both exact
 
 
 def gelu8_decode(q):
-    return q.float() * GELU8_STEP + GELU8_LO
+    return (q.float() - GELU8_ZERO) * GELU8_STEP
 
 
 def gelu8_encode(d):
-    return torch.clamp(torch.floor((d.float() - GELU8_LO) / GELU8_STEP + 0.5), 0, 255).to(torch.uint8)
+    return torch.clamp(torch.floor(d.float() * 196.0 + GELU8_ZERO + 0.5), 0, 255).to(torch.uint8)

@@ -27,6 +27,11 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, mine)
     expect = sum(gathered)
     ok = torch.allclose(g, expect, atol=1e-6) and abs(scale - 1.0 / world) < 1e-12
+    # the non-finite guard is the loss summed over the ranks: one bad rank makes EVERY rank's guard non-finite (same decision everywhere)
+    good = sync.reduce_guard(torch.tensor(1.5 + rank)); sync.finish()
+    ok = ok and abs(float(good) - sum(1.5 + r for r in range(world))) < 1e-6
+    bad = sync.reduce_guard(torch.tensor(float("nan") if rank == 1 else 2.0)); sync.finish()
+    ok = ok and not bool(torch.isfinite(bad).all()) and bad.data_ptr() == good.data_ptr()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -50,3 +55,5 @@ def test_grad_sync_single_process_is_noop():
     s = GradSync(g, [0, 5, 10], use_side_stream=False)
     s.chunk_ready(1); s.chunk_ready(0)
     assert s.finish() == 1.0 and torch.equal(g, torch.arange(10.0))
+    loss = torch.tensor(3.0)
+    assert s.reduce_guard(loss).data_ptr() == loss.data_ptr() and s.launched == 0          # single rank: the loss itself, no collective

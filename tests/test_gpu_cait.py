@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import golden_inputs as gi
-from helpers import assert_close, load_npz, micro, rel_err, report
+from helpers import assert_close, assert_elementwise, load_npz, micro, rel_err, report
 from oracle import ppf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -175,6 +175,7 @@ def test_micro_cait_against_reference_fixture():
     TOL = 2.5e-3              # measured: logits 2.6e-4, distances 8.2e-4 (gates <= 3x)
     report("micro_cait_eval", logits=rel_err(logits, z["eval/logits"]), cls_attn=rel_err(cls_attn, z["eval/cls_token_attn"]), dist=rel_err(dist, z["eval/distances"]))
     assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+    assert_elementwise(logits, z["eval/logits"], TOL, "cait eval logits")
     assert rel_err(dist, z["eval/distances"]) < TOL, rel_err(dist, z["eval/distances"])
     m.train()
     logits, aux = m(img)
@@ -268,6 +269,7 @@ def test_real_shape_cait_xxs24_train_step_vs_oracle():
     report("real_shape_cait_peaky", logits=rel_err(logits, out["logits"]), ce=rel_err(ce, parts["ce"]), cov=rel_err(cov, parts["ppc_cov"]), mean=rel_err(mean, parts["ppc_mean"]))
     # measured: logits 1.2e-4, CE 3.4e-5, PPC 1.8e-5 / 4.8e-5
     assert rel_err(logits, out["logits"]) < 4e-4
+    assert_elementwise(logits, out["logits"], 4e-4, "cait logits, real shape")
     assert rel_err(ce, parts["ce"]) < 1e-4 and rel_err(cov, parts["ppc_cov"]) < 6e-5 and rel_err(mean, parts["ppc_mean"]) < 1.5e-4
     m.flat_store().zero_grad()
     f, _, idx = m._tokens(img.cuda())

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, micro, rel_err, report
+from helpers import assert_close, assert_elementwise, micro, rel_err, report
 from oracle import ppf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -48,6 +48,7 @@ def test_micro_deit_eval_train_against_reference_fixture():
     report("micro_deit_eval", logits=rel_err(logits, z["eval/logits"]), lg=rel_err(lg, z["eval/logits_global"]), ll=rel_err(ll, z["eval/logits_local"]),
            cls_attn=rel_err(cls_attn, z["eval/cls_token_attn"]), dist=rel_err(dist, z["eval/distances"]))
     assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+    assert_elementwise(logits, z["eval/logits"], TOL, "eval logits")
     # eval `distances` VALUES (not only the shape): bf16 tokens against fp32 prototypes, error relative to the largest distance
     assert rel_err(dist, z["eval/distances"]) < TOL, rel_err(dist, z["eval/distances"])
     assert rel_err(lg, z["eval/logits_global"]) < TOL and rel_err(ll, z["eval/logits_local"]) < TOL
@@ -157,6 +158,7 @@ def test_real_shape_train_step_vs_oracle():
     # 7e-6 / 2.4e-5, PPC mean 3e-5 / 8.7e-5 with the 32-row two-pass / the 16-row one-launch attention forward (bf16 probabilities summed
     # in a different order); gates = 3 x the larger measurement
     assert rel_err(logits, out["logits"]) < 4.5e-3
+    assert_elementwise(logits, out["logits"], 4.5e-3, "logits (peaky attention)")
     assert rel_err(ce, parts["ce"]) < 8e-4 and rel_err(cov, parts["ppc_cov"]) < 7.5e-5 and rel_err(mean, parts["ppc_mean"]) < 2.6e-4
     assert n_flip <= 0.06 * my_arg.numel(), (n_flip, my_arg.numel())           # the routing itself agrees on all but near-ties (measured 22 of 800)
     assert min(c for _, c in rows.values()) > COS_FLOOR, {k: v for k, v in rows.items() if v[1] <= COS_FLOOR}

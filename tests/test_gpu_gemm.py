@@ -130,22 +130,52 @@ def test_gemm_wgrad_train_step_shapes():
     assert float(lines[-1].split()[-1]) < 1e-4, r.stdout
 
 
-@pytest.mark.parametrize("M,N,K", [(50432, 384, 1536), (50432, 384, 384), (20992, 384, 1152), (5000, 256, 128)])
-def test_gemm_224_row_tiles_nt(M, N, K):
-    """The 224 x 128 direct-to-LDS kernel (input gradients with the transposed weight shadow, PPF_GEMM_G224=2 forces it for every shape in a
-    child process): bf16 output vs an fp32 reference, edge tiles in m, bit-identical repeats."""
+_G224_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import assert_close
+from protopformer_amd import ops
+def mk(shape, scale, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(shape, device="cuda", generator=g) * scale
+for (M, N, K) in [(50432, 384, 1536), (50432, 384, 384), (20992, 384, 1152), (5000, 256, 128), (2120, 392, 192), (229, 8, 64)]:
+    a = mk((M, K), 0.5, 1).bfloat16(); b = mk((N, K), 0.1, 2).bfloat16()
+    out = ops.gemm(a, b, epi=ops.EPI_BF16)
+    ref = a.float() @ b.float().t()
+    assert_close(out.float(), ref, rtol=8e-3, atol=2e-3 * float(ref.abs().max()), what=f"nt 224 {M}x{N}x{K}")
+    for _ in range(3):
+        assert torch.equal(out, ops.gemm(a, b, epi=ops.EPI_BF16))
+# transpose-detecting: an asymmetric pattern, two row tiles, ragged n
+for (M, N) in [(448, 128), (300, 136)]:
+    a2 = torch.zeros(M, 64, device="cuda"); a2[:, 0] = torch.arange(M, device="cuda") % 17 - 8.0
+    b2 = torch.zeros(N, 64, device="cuda"); b2[:, 0] = torch.arange(N, device="cuda") % 5 - 2.0
+    o2 = ops.gemm(a2.bfloat16(), b2.bfloat16(), epi=ops.EPI_BF16).float()
+    assert torch.equal(o2, (a2[:, :1] @ b2[:, :1].t())), (M, N)
+print("G224 OK")
+"""
+
+
+def test_gemm_224_row_tiles_nt():
+    """gemm224g_kernel (224 x 128 direct-to-LDS tiles: the input gradients with the transposed weight shadow).  PPF_GEMM_G224=2 forces it
+    for EVERY eligible shape, which needs a child process (the switch is read once): bf16 output vs an fp32 reference at the train step's
+    shapes, edge tiles in m, ragged n (N = 392 / 136 / 8: the clamped B rows and the n < N store mask), a transpose-detecting pattern,
+    bit-identical repeats.  The default cost model's choice for the step's shapes is covered in-process below."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PPF_GEMM_G224="2")
+    r = subprocess.run([sys.executable, "-c", _G224_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "G224 OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 384, 1536), (50432, 384, 384)])
+def test_gemm_224_default_dispatch(M, N, K):
+    """The two shapes the default cost model sends to gemm224g_kernel, in-process."""
     from protopformer_amd import ops
     a = _mk((M, K), 0.5, 1).bfloat16(); b = _mk((N, K), 0.1, 2).bfloat16()
     out = ops.gemm(a, b, epi=ops.EPI_BF16)
     ref = a.float() @ b.float().t()
     assert_close(out.float(), ref, rtol=8e-3, atol=2e-3 * float(ref.abs().max()), what="nt 224")
-    for _ in range(3):
-        assert torch.equal(out, ops.gemm(a, b, epi=ops.EPI_BF16))
-    # transpose-detecting: an asymmetric pattern
-    a2 = torch.zeros(448, 64, device="cuda"); a2[:, 0] = torch.arange(448, device="cuda") % 17 - 8.0
-    b2 = torch.zeros(128, 64, device="cuda"); b2[:, 0] = torch.arange(128, device="cuda") % 5 - 2.0
-    o2 = ops.gemm(a2.bfloat16(), b2.bfloat16(), epi=ops.EPI_BF16).float()
-    assert torch.equal(o2, (a2[:, :1] @ b2[:, :1].t()))
+    assert torch.equal(out, ops.gemm(a, b, epi=ops.EPI_BF16))
 
 
 @pytest.mark.parametrize("n_out,n_in,rows", [(1536, 384, 8192), (1152, 384, 4160), (384, 1536, 8192), (1032, 392, 2120), (400, 1288, 1992), (768, 384, 4096)])

@@ -7,7 +7,7 @@ fp32 operands everywhere, so any disagreement beyond 1e-3 is a kernel or orchest
 import pytest
 import torch
 
-from helpers import assert_close, build_micro, micro, rel_err
+from helpers import assert_close, assert_elementwise, build_micro, micro, rel_err
 from oracle import ppf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -29,6 +29,7 @@ def test_precise_forward_and_loss_match_reference_fixture(name):
         ref_idx = torch.from_numpy(z["eval/cls_token_attn"]).topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
         assert torch.equal(m._tokens(img)[2].cpu().long(), ref_idx), "reserved-token indices must be bit-exact"
         assert rel_err(logits, z["eval/logits"]) < TOL, rel_err(logits, z["eval/logits"])
+        assert_elementwise(logits, z["eval/logits"], TOL, "fp32 mode eval logits")
         assert rel_err(lg, z["eval/logits_global"]) < TOL and rel_err(ll, z["eval/logits_local"]) < TOL
         # distances: d = x2 - 2xp + p2 cancels, so compare on the scale of its terms (SURVEY 8(c) tolerances)
         d_ref = torch.from_numpy(z["eval/distances"])
@@ -41,6 +42,7 @@ def test_precise_forward_and_loss_match_reference_fixture(name):
         logits, aux = m(img)
         assert aux[0] is None and aux[4] == 16
         assert rel_err(logits, z["train/logits"]) < TOL
+        assert_elementwise(logits, z["train/logits"], TOL, "fp32 mode train logits")
         assert_close(aux[3], z["train/cls_attn_rollout"], rtol=TOL, atol=1e-7, what="cls_attn_rollout")
         ce = CrossEntropyLoss()(logits, label)
         cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label)
@@ -98,6 +100,7 @@ def test_precise_baseline_heads_vs_oracle(arch, k, layer, C, gpc, P, Dp):
     if float((srt[:, k - 1] - srt[:, k]).min()) > 1e-5 * float(srt.max()):          # tie-free at the boundary: indices must be exact
         assert torch.equal(m._ppc_cache[1].cpu().long(), out["reserve_idx"])
     assert rel_err(logits, out["logits"]) < TOL, rel_err(logits, out["logits"])
+    assert_elementwise(logits, out["logits"], TOL, "fp32 mode logits, real head")
     assert rel_err(ce, parts["ce"]) < TOL and rel_err(cov, parts["ppc_cov"]) < TOL and rel_err(mean, parts["ppc_mean"]) < TOL
     far = out["distances"] >= 0.05
     assert_close(aux[2].cpu()[far], out["total_proto_act"][far], rtol=TOL, atol=1e-5, what="total_proto_act (d >= 0.05)")
