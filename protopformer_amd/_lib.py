@@ -17,6 +17,7 @@ SIGS = {
     "ppf_rowgemm_resid_ln": "pp" "iiiiii" "p" "pp" "pi" "pp" "pp" "ppp" "f" "s",
     "ppf_rowgemm_lnbwd": "pp" "iiiiii" "pppp" "ppp" "pi" "pp" "pz" "s",
     "ppf_rowgemm_colsum": "p" "iii" "ppp" "s",
+    "ppf_mlp_fwd": "ppppp" "iiii" "pp" "pp" "pi" "p" "p" "ppppp" "f" "s",
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",
     "ppf_gemm_probe_read": "pppp",
@@ -125,6 +126,8 @@ def lib():
         _lib.ppf_clip_grad_blocks.argtypes = []
         _lib.ppf_rowgemm_supported.restype = ctypes.c_int
         _lib.ppf_rowgemm_supported.argtypes = [ctypes.c_int] * 3
+        _lib.ppf_mlp_fwd_supported.restype = ctypes.c_int
+        _lib.ppf_mlp_fwd_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_attn_fwd_hm_supported.restype = ctypes.c_int
         _lib.ppf_attn_fwd_hm_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_th_fused_supported.restype = ctypes.c_int

@@ -156,6 +156,20 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         else:
             x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
             n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        mlp_rows = (Nc + 1) // 2                                               # half-sample tiles (<= 112 rows) for the one-launch MLP
+        if fused and ops.mlp_fwd_ok(D, hid, mlp_rows):
+            # opt-in (PPF_MLP_FUSED=1): fc1 -> GELU -> fc2 -> residual + DropPath -> next LayerNorm in ONE launch (csrc/mlpfwd.hip)
+            nxt = feats.blocks[i + 1] if (i + 1 < nblk and not (compact and i + 1 == reserve_layer)) else None
+            x2, nn1, nm1, nr1, g, h = ops.mlp_fwd(n2, store.w16(blk.mlp.fc1.weight), blk.mlp.fc1.bias, store.w16(blk.mlp.fc2.weight), blk.mlp.fc2.bias,
+                                                  x1, mlp_rows, rowscale=s2, rows_per_group=Nc, ln_w=nxt.norm1.weight if nxt is not None else None,
+                                                  ln_b=nxt.norm1.bias if nxt is not None else None, eps=LN_EPS)
+            pre = (nn1, nm1, nr1) if nxt is not None else None
+            if save:
+                layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ao=ao, rowmax=rowmax, zinv=zinv, x1=x1, n2=n2,
+                                   mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2, N=Nc, eps_n=eps_n,
+                                   rows=rows if (compact and i == reserve_layer) else None))
+            x = x2
+            continue
         h = torch.empty((M, hid), dtype=torch.uint8, device=x.device)            # gelu'(pre-activation), 8-bit codes (csrc/gemm_common.h)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
         if fused:

@@ -148,6 +148,39 @@ def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_pe
     return xout, n, mean, rstd
 
 
+def mlp_fwd_supported(D, hid, rows_per_tile):
+    """True when csrc/mlpfwd.hip takes an MLP of width D / hidden width hid in tiles of rows_per_tile rows."""
+    return bool(_lib.lib().ppf_mlp_fwd_supported(int(D), int(hid), int(rows_per_tile)))
+
+
+def mlp_fwd_ok(D, hid, rows_per_tile):
+    """The train step uses the fused MLP forward only when asked (PPF_MLP_FUSED=1): measured 290-305 us per deit_small layer against 214 us
+    for the two launches it replaces (profiles/r5_mlp_fused.txt) -- correct, tested, and slower."""
+    return os.environ.get("PPF_MLP_FUSED", "0") != "0" and mlp_fwd_supported(D, hid, rows_per_tile)
+
+
+def mlp_fwd(a, w1, b1, w2, b2, res, rows_per_tile, rowscale=None, rows_per_group=1, ln_w=None, ln_b=None, eps=1e-6, colscale=None, aux_out=None):
+    """timm Mlp + residual + the following LayerNorm in one launch (csrc/mlpfwd.hip): h = gelu(a @ w1^T + b1) (bf16, saved for backward),
+    dgelu = gelu'(.) as 8-bit codes, x_out = res + rowscale * colscale * (h @ w2^T + b2) (fp32), n = bf16(LN(x_out)) with mean / rstd.
+    Returns (x_out, n, mean, rstd, h, dgelu) (n, mean, rstd None without a LayerNorm)."""
+    _chk(a, torch.bfloat16), _chk(w1, torch.bfloat16), _chk(w2, torch.bfloat16), _chk(res, torch.float32)
+    M, D = a.shape
+    hid = w1.shape[0]
+    assert w1.shape[1] == D and tuple(w2.shape) == (D, hid), "w1 [hid, D], w2 [D, hid]"
+    dev = a.device
+    h = torch.empty((M, hid), dtype=torch.bfloat16, device=dev)
+    dg = torch.empty((M, hid), dtype=torch.uint8, device=dev)
+    xout = torch.empty((M, D), dtype=torch.float32, device=dev)
+    n = mean = rstd = None
+    if ln_w is not None:
+        n = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    _lib.call("ppf_mlp_fwd", a, w1, b1, w2, b2, M, D, hid, rows_per_tile, h, dg, res, xout, rowscale, rows_per_group, colscale, aux_out,
+              ln_w, ln_b, n, mean, rstd, float(eps))
+    return xout, n, mean, rstd, h, dg
+
+
 def rowgemm_lnbwd(a, b, x, mean, rstd, w, dw, db, rows_per_tile, dres_in=None, dx_out=None, cast_out=None, rowscale=None, rows_per_group=1,
                   lane=None, defer_reduce=False, colscale=None, branch=None, dcolscale=None):
     """dn = a @ b^T is the gradient w.r.t. the output of LN(x); dx_out = dres_in + LN'(dn) (fp32), cast_out = bf16(rowscale * dx_out);
