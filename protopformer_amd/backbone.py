@@ -15,8 +15,6 @@ from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, 
 
 LN_EPS = 1e-6
 _KEEP_CACHE = {}
-# Measurement only (results are WRONG): PPF_KNOCKOUT=wgrad,headmean,thr,attnbwd,... skips those launches so that scripts/gpu/ab_step.py can
-# price what each family costs INSIDE the two-stream step (stand-alone kernel times do not add up there).
 # PPF_ROWGEMM_FWD / PPF_ROWGEMM_BWD = 0 / 1: keep / use the full-row GEMMs with fused LayerNorm in the forward / backward pass (A/B).
 # Backward default "auto" (measured, profiles/r3_rowgemm.txt section 7): in the backward pass the full-row kernels own whole CUs while the
 # weight-gradient GEMMs of the side stream want to share them -- a win where the step is launch-bound (deit_tiny batch 128: +7.5 %),
@@ -28,7 +26,6 @@ _ROW_BWD_MAX_ELEMS = 12_000_000          # rows x width of the residual stream u
 
 def _row_bwd(M, D):
     return _ROW_BWD == "1" or (_ROW_BWD == "auto" and M * D <= _ROW_BWD_MAX_ELEMS)
-_KO = set(filter(None, os.environ.get("PPF_KNOCKOUT", "").replace("+", ",").split(",")))
 
 
 def droppath_scales(rates, B, device, training):
@@ -130,15 +127,15 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         # the head-mean map of a layer in front of the reservation (the rollout's input) comes out of the attention launch itself where the
         # one-launch kernel covers the shape; otherwise it is recomputed from the saved statistics on the side stream
-        hm_fused = i < reserve_layer and "headmean" not in _KO and ops.attn_fwd_hm_ok(H, Nc, D)
+        hm_fused = i < reserve_layer and ops.attn_fwd_hm_ok(H, Nc, D)
         ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, Nc, D, policy=policy, self_keep=True, eps_n=eps_n, headmean=hm[i] if hm_fused else None)
         if i < reserve_layer:
             def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i, hm_fused=hm_fused):
-                if "headmean" not in _KO and not hm_fused:
+                if not hm_fused:
                     ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
                 if recs is not None:
                     ops.rollout_compact_layer(hm[i], recs[i], N)   # the r-independent part of this layer's rollout step, off the critical path
-                elif side_thr and "thr" not in _KO:
+                elif side_thr:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
             # (PPF_ROLLOUT_BATCH = n: the side launches of n consecutive layers go out under one main-stream event record)
             # ... except in front of the reservation: the chain needs the last layers' thresholds first, and the main stream waits for it
@@ -320,8 +317,6 @@ _ROLL_BATCH = max(1, int(os.environ.get("PPF_ROLLOUT_BATCH", "3")))      # 3: +0
 def _wgrad(store, dy16, x16, weight, bias=None, defer=False):
     """dW[N,K] += dy^T x (deterministic split-K into the flat grad), optional fused bias grad (column sums of dy); queued on
     the weight-gradient lane (defer: launched with the next submit, see above)."""
-    if "wgrad" in _KO:
-        return
     gw = store.grad_view(weight)
     gb = store.grad_view(bias) if bias is not None else None
     wgrad_lane(store).submit(lambda: ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
@@ -438,8 +433,7 @@ def deit_backward(ppnet, store, saved, df):
             dao = ops.rowgemm_bf16(dyb, wpt, rpt)
         else:
             dao = _dgrad(dyb, store, blk.attn.proj.weight, wpt)
-        dqkv = (torch.empty_like(L["qkv"]) if "attnbwd" in _KO else
-                ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True, eps_n=L["eps_n"]))
+        dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True, eps_n=L["eps_n"])
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
         dn1 = None if fused else _dgrad(dqkv, store, blk.attn.qkv.weight, wqt)
         if i > 0:

@@ -39,7 +39,6 @@ struct AttnParams {
     int self_keep;         // 1: a masked query still attends to itself (DeiT); 0: CaiT class attention
     float scale;
     float eps_c;           // eps / N_ref: the +eps/N term of the policy softmax; N_ref = tokens BEFORE reservation (compacted blocks pass it)
-    int ko;                // measurement only (PPF_ATTN_KO bit mask, results wrong): phases of attn_bwd_stream_kernel knocked out
 };
 
 __device__ __forceinline__ int kswz(int row) {
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
     // workgroups of a sample read the same K / V: they are placed on the SAME XCD (dispatch ids L and L + 8; observed placement L % 8,
     // speed only) so that the second read is served by that XCD's L2 instead of crossing the fabric again
     int b = blockIdx.y, x = blockIdx.x;
-    if (gridDim.x == 2 && (gridDim.y & 7) == 0 && !(p.ko & 64)) {
+    if (gridDim.x == 2 && (gridDim.y & 7) == 0) {
         const int L = blockIdx.x + 2 * blockIdx.y, r = L & 15;
         b = (L >> 4) * 8 + (r & 7); x = r >> 3;
     }
@@ -906,13 +905,13 @@ __global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnP
         };
 #pragma unroll 1
         for (int i = 0; i < NT; ++i) {
-            if (active && !(p.ko & 1)) { p1(i); p2(i); }
+            if (active) { p1(i); p2(i); }
             __syncthreads();                           // the next step's owner of each query tile sees this step's sums
         }
         // ---- every wave is past the last pair: the images are dead.  The next item's loads go out first, this item's results after them.
         const int nxt = item + gridDim.x;
-        if (nxt < nitems && !(p.ko & 4)) { issue_images(nxt); load_rows(nxt); }
-        if (active && !(p.ko & 2)) {
+        if (nxt < nitems) { issue_images(nxt); load_rows(nxt); }
+        if (active) {
             bf16_t* dst = p.dqkv + ((size_t)b * N + r0) * p.ld + h * HD;
             const float* qa = dqacc + wave * DQT + lane * 4;
 #pragma unroll
@@ -967,8 +966,6 @@ int fill(AttnParams& p, const void* qkv, int B, int H, int N, int D, const float
     p = AttnParams();
     p.qkv = (const bf16_t*)qkv; p.ld = 3 * D; p.policy = policy; p.rowmax = rowmax; p.zinv = zinv; p.B = B; p.H = H; p.N = N; p.D = D;
     p.self_keep = self_keep; p.scale = 1.0f / sqrtf((float)(D / H));
-    static const int ko = getenv("PPF_ATTN_KO") ? atoi(getenv("PPF_ATTN_KO")) : 0;
-    p.ko = ko;
     p.eps_c = SOFTMAX_EPS / (float)(eps_n > 0 ? eps_n : N);
     return 0;
 }

@@ -250,16 +250,8 @@ __global__ __launch_bounds__(NTHREADS, MT == 2 ? 3 : 2) void gemm_kernel(const G
                 // this and the next PD-1 tiles are multiplied (past the end: re-read of the last tile, never stored -- keeps the
                 // loop body branch-free so that the compiler's vmcnt counting leaves PD-1 tiles in flight)
                 const int k0 = kbeg + min(kt + PD, nk - 1) * BK;
-#ifdef PPF_KO_WGRAD_HALF_LOADS                                   // knock-out build (wrong results): every second K tile re-uses the registers
-                if (!(TA && TB && (kt & 1)))
-#endif
-                {
                 ma[u] = IOA::gload(ra[u], p.A, p.lda, p.M, m0, k0, kend, tid, p.kpad);
                 mb[u] = IOB::gload(rb[u], p.B, p.ldb, p.N, n0, k0, kend, tid, p.kpad);
-                }
-#ifdef PPF_KO_WGRAD_HALF_MFMA
-                if (TA && TB && (kt & 1)) { __syncthreads(); if (kt + 1 < nk) { IOA::sstore(ra[(u + 1) % PD], ma[(u + 1) % PD], tA, tid); IOB::sstore(rb[(u + 1) % PD], mb[(u + 1) % PD], tB, tid); } __syncthreads(); continue; }
-#endif
             }
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {

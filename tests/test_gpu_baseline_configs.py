@@ -86,7 +86,7 @@ def test_baseline_config_small_batch_vs_oracle(name):
     # losses on the bf16 product path at the BASELINE shapes; gates at <= 3x the measurements
     # (deit_base, D = 768: logits 3.3e-4, loss 1.7e-5, PPC 2.5e-5 / 9.0e-5, activations 2.1e-3)
     assert_elementwise(logits, out["logits"], 1e-3, "logits vs the oracle on the same reservation")
-    assert e["logits_own_reservation"] < 0.1, e          # reported: a handful of swapped near-tied tokens move the logits
+    assert e["logits_own_reservation"] < 3.5e-3, e          # measured 6.7e-4 ... 1.1e-3: a handful of swapped near-tied tokens move the logits
     assert e["logits"] < 1e-3 and e["ce"] < 3e-5 and e["loss"] < 5e-5 and e["cov"] < 8e-5 and e["mean"] < 3e-4 and e["act"] < 6e-3, e
     # the rollout map multiplies 11 (24) bf16-derived attention maps: measured 5.3e-2 / 5.8e-2 / 2.0e-3 of its maximum
     assert e["cls_attn"] < 0.1, e
@@ -94,7 +94,7 @@ def test_baseline_config_small_batch_vs_oracle(name):
     # (deit_small), 3 / 4 / 3 (deit_tiny / cait_xxs24 / deit_base) -- gate at 10 % of the reserved tokens
     assert n_diff <= 0.1 * my_idx.numel(), (n_diff, my_idx.numel())
     # deit_base: a near-tied max-pool arg-max routes one prototype's gradient to another token than in the fp32 run (the documented
-    # discontinuity, test_gpu_e2e.py); every tensor then shares the same cosine, 0.983-0.986 (scripts/gpu/diag_base.py)
+    # discontinuity, test_gpu_e2e.py); every tensor then shares the same cosine, 0.983-0.986 (per-tensor dump of round 4, git history: scripts/gpu/diag_base.py)
     floor = 0.97 if name == "deit_base" else 0.9992
     assert len(cos) > 100 and worst > floor, {k_: v for k_, v in cos.items() if v <= floor}
 
