@@ -28,7 +28,7 @@ def rnd(*shape):
 cases = []
 x = rnd(M, D); w_qkv = rnd(3 * D, D); w_proj = rnd(D, D); w1 = rnd(4 * D, D); w2 = rnd(D, 4 * D)
 res = torch.randn(M, D, device=dev); bias = torch.randn(4 * D, device=dev)
-h = torch.empty(M, 4 * D, dtype=torch.bfloat16, device=dev); g = rnd(M, 4 * D); dy = rnd(M, D); dqkv = rnd(M, 3 * D); dh = rnd(M, 4 * D)
+h = torch.empty(M, 4 * D, dtype=torch.uint8, device=dev); g = rnd(M, 4 * D)       # gelu' codes (one byte per element); dy = rnd(M, D); dqkv = rnd(M, 3 * D); dh = rnd(M, 4 * D)
 out_res = torch.empty(M, D, device=dev)
 cases.append(("fwd qkv   NT bf16  N=1152 K=384", lambda: ops.gemm(x, w_qkv, epi=ops.EPI_BF16, bias=bias[:3 * D]), 2 * M * 3 * D * D, (M * D + M * 3 * D) * 2))
 cases.append(("fwd proj  NT resid N=384  K=384", lambda: ops.gemm(x, w_proj, epi=ops.EPI_RESID, bias=bias[:D], res=res, out=out_res), 2 * M * D * D, M * D * 2 + M * D * 8))
