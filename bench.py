@@ -184,7 +184,7 @@ def cpu_baseline():
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
     (profiles/*_pmc_traffic.json, newest round first: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction)."""
-    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
