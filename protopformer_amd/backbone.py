@@ -326,10 +326,18 @@ def _wgrad(store, dy16, x16, weight, bias=None, defer=False):
 _DGRAD_NT = os.environ.get("PPF_DGRAD_NT", "1") != "0"
 
 
-def _dgrad(dy16, store, weight, wt):
+# Round 5: the input gradients of fc1 and qkv (N = 384 outputs, K = 1536 / 1152) through the PLAIN full-row GEMM (rowgemm_bf16: double-buffered
+# LDS-DMA stages, 57 / 46 us stand-alone) instead of the 224 x 128 tiles (single-buffered, ~100 us), the LayerNorm backward staying its own
+# launch: +1.0 % same-box at deit_small (fc1 +0.4, qkv +0.6, proj -0.2, all three +0.8; profiles/r5_dgrad_row.txt).  Bit mask fc1 (1) / qkv (2) / proj (4).
+_DGRAD_ROW = int(os.environ.get("PPF_DGRAD_ROW", "3"))
+
+
+def _dgrad(dy16, store, weight, wt, rows=None, which=0):
     """dx = dy W as bf16.  With the transposed weight shadow (FlatStore.register_transposed) both operands are contraction-contiguous and
     the product can take the 224 x 128 direct-to-LDS kernel (csrc/gemm_bf16.hip gemm224g_kernel: one round of the chip instead of 1.54 for
     the N = 384 outputs); otherwise the [K][N] weight is read transposed by the generic kernel.  PPF_DGRAD_NT=0: always the latter (A/B)."""
+    if wt is not None and (_DGRAD_ROW & which) and rows is not None and ops.rowgemm_ok(wt.shape[0], wt.shape[1], rows):
+        return ops.rowgemm_bf16(dy16, wt, rows)
     if wt is not None and _DGRAD_NT:
         return ops.gemm(dy16, wt, epi=EPI_BF16)
     return ops.gemm(dy16, store.w16(weight), trans_b=True, epi=EPI_BF16)
@@ -422,7 +430,7 @@ def deit_backward(ppnet, store, saved, df):
             ops.rowgemm_lnbwd(dh, w1t, L["x1"], L["mean2"], L["rstd2"], blk.norm2.weight, store.grad_view(blk.norm2.weight), store.grad_view(blk.norm2.bias),
                               rpt, dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl, lane=lane, defer_reduce=True)
         else:
-            dn2 = _dgrad(dh, store, blk.mlp.fc1.weight, w1t)
+            dn2 = _dgrad(dh, store, blk.mlp.fc1.weight, w1t, Nl, 1)
             lnb(dn2, L["x1"], blk.norm2.weight, L["mean2"], L["rstd2"], store.grad_view(blk.norm2.weight),
                               store.grad_view(blk.norm2.bias), dres_in=dx, dx_out=dx, cast_out=dyb, rowscale=L["s1"], rows_per_group=Nl,
                               dbias_next=store.grad_view(blk.attn.proj.bias))
@@ -432,10 +440,10 @@ def deit_backward(ppnet, store, saved, df):
         if fused:
             dao = ops.rowgemm_bf16(dyb, wpt, rpt)
         else:
-            dao = _dgrad(dyb, store, blk.attn.proj.weight, wpt)
+            dao = _dgrad(dyb, store, blk.attn.proj.weight, wpt, Nl, 4)
         dqkv = ops.attn_bwd(L["qkv"], L["ao"], dao, L["rowmax"], L["zinv"], B, feats.num_heads, Nl, D, policy=L["policy"], self_keep=True, eps_n=L["eps_n"])
         _wgrad(store, dqkv, L["n1"], blk.attn.qkv.weight, blk.attn.qkv.bias)
-        dn1 = None if fused else _dgrad(dqkv, store, blk.attn.qkv.weight, wqt)
+        dn1 = None if fused else _dgrad(dqkv, store, blk.attn.qkv.weight, wqt, Nl, 2)
         if i > 0:
             prev = feats.blocks[i - 1]
             dyb, dyb_alt = next_dyb(dyb, dyb_alt)
