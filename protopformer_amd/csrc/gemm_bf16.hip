@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm224g_kernel(const GemmParams 
 
 // Takes a plain bf16-output NT product when 224-row tiles (three workgroups per CU) need less CU time than 128-row tiles (three per CU in
 // the generic kernel, four in the direct-to-LDS one); a partly filled last round is priced as a whole round (a round lasts a tile's
-// latency however many CUs it fills: 1.54 rounds measured as 2), half a round below 25 % fill.  K >= 384: with three K tiles per
+// latency however many CUs it fills: 1.54 rounds measured as 2), half a round below 25 % fill.  K >= 768 (384 until round 5): with three K tiles per
 // workgroup (the D = 192 models) the larger tile's prologue / epilogue outweigh the saved round -- fc1 + GELU and the x gelu' input
 // gradient of deit_tiny / cait_xxs24 (N = 768, K = 192; 1 182 vs 678 tiles) were measured 1.1 % SLOWER per step with this kernel.
 bool g4_eligible(const GemmParams& p);
@@ -676,7 +676,7 @@ bool g224_eligible(const GemmParams& p, int epi) {
     if (!mode || epi != EPI_BF16 || p.bias != nullptr || p.kpad || p.K % BK != 0 || p.N % 8 != 0 || (p.ldc & 7) != 0) return false;
     if ((long long)p.M * p.lda >= (1ll << 30) || (long long)p.N * p.ldb >= (1ll << 30)) return false;
     if (mode == 2) return true;
-    if (p.K < 384) return false;
+    if (p.K < 768) return false;                 // round 5: the K = 384 input gradient of proj is +0.8 % of the deit_small step on 128 x 128 tiles (six K tiles do not pay for the larger tile's prologue / epilogue)
     static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long long tn = (p.N + BN - 1) / BN;
     const long long t128 = (long long)((p.M + BM - 1) / BM) * tn, t224 = (long long)((p.M + G224_ROWS - 1) / G224_ROWS) * tn;

@@ -169,7 +169,7 @@ def test_gemm_224_row_tiles_nt():
 
 @pytest.mark.parametrize("M,N,K", [(50432, 384, 1536), (50432, 384, 384)])
 def test_gemm_224_default_dispatch(M, N, K):
-    """The two shapes the default cost model sends to gemm224g_kernel, in-process."""
+    """Two N = 384 input-gradient shapes in-process under the default cost model (K = 1536 takes gemm224g_kernel, K = 384 the 128 x 128 tiles since round 5)."""
     from protopformer_amd import ops
     a = _mk((M, K), 0.5, 1).bfloat16(); b = _mk((N, K), 0.1, 2).bfloat16()
     out = ops.gemm(a, b, epi=ops.EPI_BF16)
