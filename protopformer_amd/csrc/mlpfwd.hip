@@ -1,18 +1,25 @@
 // Fused MLP forward for gfx950 (round 5):  x2 = x1 + DropPath(LayerScale(gelu(n2 W1^T + b1) W2^T + b2)),  n' = LayerNorm(x2)
 // -- timm's Mlp + the residual add + the LayerNorm that follows it (deit:76-81, cait:153-157) -- in ONE launch.  The hidden layer
 // h = gelu(.) and gelu'(.) are still WRITTEN (backward needs them: the fc2 weight gradient and the x gelu' input gradient) but never
-// read back in the forward pass: the 155 MB (deit_small, batch 256) that the fc2 product re-read per layer are gone, and so is a launch.
+// read back in the forward pass: the 155 MB (deit_small, batch 256) that the fc2 product re-reads per layer are gone, and so is a launch.
+//
+// STATUS: verified (tests/test_gpu_rowgemm.py::test_mlp_fwd_*, tests/test_gpu_e2e.py::test_fused_mlp_forward_matches_two_launch_path) and
+// SLOWER than the two launches it replaces: 290-305 us vs 214 us per deit_small layer, -10.3 % of the train step.  The host mirror calls it
+// only under PPF_MLP_FUSED=1.  Knock-out table, cost model and the code-generation traps met on the way: profiles/r5_mlp_fused.txt.
 //
 // Why this shape (profiles/r5_l2_shared_tile.txt): a CU's memory pipe delivers L2 hits at ~109 GB/s and anything that comes over
 // the fabric (HBM / memory-side cache) at ~26 GB/s when every CU streams, and it ADDS the two; the L2 of an XCD (4 MiB for 32 CUs)
 // cannot keep a 197-row activation tile per CU (156 KiB x 32) next to the weight stream.  So the activation tile lives in LDS:
-//   * one 256-thread workgroup (4 waves, one per SIMD, up to 512 VGPRs) per tile of <= 112 rows (7 m-tiles; the host passes half a
-//     sample), A = the tile's LayerNorm output [112][D] bf16 resident in LDS (84 KiB at D = 384), fetched ONCE;
+//   * one 256-thread workgroup (4 waves, ONE per SIMD, up to 512 registers each) per tile of <= 112 rows (7 m-tiles; the host passes half
+//     a sample), A = the tile's LayerNorm output [112][D] bf16 resident in LDS (84 KiB at D = 384), fetched ONCE;
 //   * the hidden layer in chunks of 64 units: P = A W1c^T (contraction D, MFMA 16x16x32, 2 x 2 waves), bias + GELU in registers,
 //     P as bf16 into a 14 KiB LDS image + h / gelu' straight to HBM (16- / 8-byte pieces, 64 / 32 contiguous bytes per row),
-//     then out += P W2c^T (contraction 64; a wave owns 48 output columns in each 192-column half, all 7 m-tiles: 168 accumulator VGPRs);
+//     then out += P W2c^T (contraction 64; a wave owns 48 output columns in each 192-column half, all 7 m-tiles: 168 accumulator registers);
+//   * skewed by one chunk: the GELU of chunk c rides on the MFMA stream of chunk c - 1's second product; h / gelu' stores leave BEHIND the
+//     next stage boundary (a store in front of an s_waitcnt vmcnt(0) makes it wait for the write acknowledge);
 //   * the weights stream through a double-buffered ring of 24 KiB stages (W1c as 64 rows x three 128-byte K slabs, W2c as 192 rows x
-//     128 bytes: 24 one-KiB LDS-DMA pieces each, six per wave), one s_waitcnt + barrier per stage, pieces spread over the MFMA stream;
+//     128 bytes: 24 one-KiB LDS-DMA pieces each, six per wave, issued in the first half of the previous stage), one s_waitcnt + barrier
+//     per stage; buffer-descriptor addressing (SGPR base + 32-bit VGPR offset + SGPR offset) and a compile-time operand kind per call site;
 //   * the epilogue is csrc/rowgemm.hip's RG_RESID_LN: 64 rows at a time through an fp32 LDS image, row statistics by shuffles.
 // W1 rows are fetched in the order that makes a lane's two accumulator tiles 8 CONSECUTIVE hidden units (MFMA row 4q + r of tile j <->
 // unit 8q + 4j + r), so h leaves as one 16-byte store per lane and m-tile and lands in the image as one ds_write_b128.
