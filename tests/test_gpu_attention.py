@@ -154,3 +154,33 @@ def test_attn_bwd_streaming_many_items_per_workgroup():
     scale = float(ref.abs().max())
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert_close(dqkv[:, sl], ref[:, sl], rtol=2e-2, atol=1.5e-2 * scale, what=name)
+
+
+def test_path_probe_counts_launches_and_algorithmic_work():
+    """ppf_path_probe / ppf_path_probe_read (bench.py's roofline.named_path): HIP events around the attention forward / backward launches,
+    the algorithmic flops and bytes DESIGN.md section 4 states, nothing recorded while the probe is off."""
+    import ctypes
+    from protopformer_amd import _lib, ops
+    B, H, N, D = 4, 6, 197, 384
+    qkv = (torch.randn(B * N, 3 * D, device="cuda") * 0.5).bfloat16()
+
+    def read(tag):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.call("ppf_path_probe_read", tag, ctypes.addressof(ms), ctypes.addressof(n), ctypes.addressof(fl), ctypes.addressof(by))
+        return ms.value, int(n.value), fl.value, by.value
+
+    ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, N, D)                  # probe off
+    _lib.call("ppf_path_probe", 1)
+    assert read(0)[1] == 0 and read(1)[1] == 0
+    for _ in range(3):
+        ao, rowmax, zinv = ops.attn_fwd(qkv, B, H, N, D)
+    ops.attn_bwd(qkv, ao, torch.randn_like(ao), rowmax, zinv, B, H, N, D)
+    torch.cuda.synchronize()
+    _lib.call("ppf_path_probe", 0)
+    ops.attn_fwd(qkv, B, H, N, D)                                     # probe off again: not counted
+    ms, n, fl, by = read(0)
+    assert n == 3 and ms > 0 and fl == 3 * 4.0 * B * H * N * N * (D // H) and by >= 3 * 8.0 * B * N * D
+    ms, n, fl, _ = read(1)
+    assert n == 1 and ms > 0 and fl == 10.0 * B * H * N * N * (D // H)
+    assert read(2)[1] == 0
+    _lib.call("ppf_path_probe", 2)

@@ -419,6 +419,17 @@ def test_nonfinite_loss_skips_the_update_and_raises_the_flag():
     with pytest.raises(SystemExit):
         train_one_epoch(m, crit, [(img, label)] * 3, opt, "cuda", epoch=20, log_every=2, logger=logs.append)
     assert any("stopping training" in s for s in logs)
+    # the raised flag also stops an epoch that never reaches a log read, and no checkpoint is written from that state (round 5)
+    from protopformer_amd.engine import save_checkpoint
+    logs2 = []
+    with pytest.raises(SystemExit):
+        train_one_epoch(m, crit, [(img, label)], opt, "cuda", epoch=20, log_every=1000, logger=logs2.append)
+    assert any("stopping training" in s for s in logs2)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        with pytest.raises(RuntimeError, match="non-finite"):
+            save_checkpoint(os.path.join(d, "ck.pth"), m, opt, None, 0)
+        assert not os.path.exists(os.path.join(d, "ck.pth"))
 
 
 def test_block_row_ppc_gradient_equals_dense_exchange_also_when_shared():
