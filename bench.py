@@ -353,6 +353,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path)")
     cfg = dict(CONFIGS[args.config])
     batch = args.batch or cfg["batch"]
+    # test-only: PPF_BENCH_ONE_GPU=1 puts every rank on cuda:0 and PPF_BENCH_BACKEND=gloo swaps the process-group backend, so that the whole
+    # multi-rank flow of this file (broadcast, chunked all-reduce, guard, replay with live collectives, probe legs) runs on a 1-GPU box
+    # (scripts/gpu/bench_two_ranks_check.sh: ~10 s per step through gloo, too slow for the test suite); RCCL itself refuses two ranks on one device
+    if os.environ.get("PPF_BENCH_ONE_GPU", "0") != "0":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if args.wgrad_alone:
         print(json.dumps(wgrad_uncontended(cfg, batch, torch.device("cuda", local_rank))), flush=True)
@@ -361,7 +366,11 @@ def main():
     if world > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("PPF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
 
     from protopformer_amd import _lib, ops
     from protopformer_amd.engine import GraphedTrainStep, ReplayedTrainStep, train_one_step
@@ -442,17 +451,19 @@ def main():
         probe_note = "HIP events around every launch of 3 host-enqueued steps after the timed region (graph nodes cannot be timed)"
     # the kernels the north star names (attention forward / backward, prototype forward): in-step HIP-event time over 3 more steps of
     # the same kind AFTER the timed region (the ~50 extra event records per step must not touch `value`)
+    # EVERY rank runs the three steps (they contain the gradient collectives); rank 0 reports its own kernels' times.
     named = None
-    if rank == 0 and os.environ.get("PPF_BENCH_PROBE", "1") != "0":
-        try:
-            _lib.call("ppf_path_probe", 1)
-            for _ in range(3):
-                step() if graphed is None else train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
-            torch.cuda.synchronize()
-            _lib.call("ppf_path_probe", 0)
-            named = named_path_report(_lib, 3)
-        except Exception as e:                                          # informational leg: never takes the line down
-            named = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+    if os.environ.get("PPF_BENCH_PROBE", "1") != "0":
+        _lib.call("ppf_path_probe", 1)
+        for _ in range(3):
+            step() if graphed is None else train_one_step(model, crit, img, label, opt, epoch=20, grad_sync=sync)
+        torch.cuda.synchronize()
+        _lib.call("ppf_path_probe", 0)
+        if rank == 0:
+            try:
+                named = named_path_report(_lib, 3)
+            except Exception as e:                                      # informational leg: never takes the line down
+                named = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

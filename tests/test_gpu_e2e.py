@@ -278,3 +278,4 @@ def test_fused_mlp_forward_matches_two_launch_path(monkeypatch):
     report("fused_mlp_vs_two_launches_tiny", logits=rel_err(a["logits"], b["logits"]), loss=abs(a["loss"] - b["loss"]) / abs(b["loss"]), cos=cos,
            reserved_differing=int((a["idx"] != b["idx"]).sum()))
     assert rel_err(a["logits"], b["logits"]) < 1e-3 and abs(a["loss"] - b["loss"]) < 1e-4 * abs(b["loss"]) and cos > 0.9995, (rel_err(a["logits"], b["logits"]), cos)
+
