@@ -87,6 +87,17 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
                           int trans_b, int out_f32, float alpha, int batch_outer, int batch_inner, int64_t sa_o, int64_t sa_i,
                           int64_t sb_o, int64_t sb_i, int64_t sc_o, int64_t sc_i, int kpad, ppf_stream_t stream);
 
+/* ---- fp32 verification mode, backward (csrc/precise.hip, round 5; DeiT): never on the measured path -----------------------------
+ * LayerNorm backward with the statistics recomputed from x (rows of dy <-> rows row_map[r] of x, dx_out written at the x rows, dw / db by
+ * fp32 atomics); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale); column sums; Attention backward with the
+ * policy softmax of deit:29-43 (scratch: B*H*2*N*N floats). */
+int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
+                          int rows, int D, float eps, ppf_stream_t stream);
+int ppf_ew_bwd_f32(int kind, const float* a, const float* b, float* out, const float* rowscale, int rows_per_group, int M, int N, ppf_stream_t stream);
+int ppf_colsum_f32(const float* in, float* out, int M, int N, ppf_stream_t stream);
+int ppf_attn_bwd_f32(const float* qkv, const float* dout, const float* policy, float* dqkv, float* scratch, int B, int H, int N, int D, int self_keep,
+                     int eps_n, ppf_stream_t stream);
+
 /* ---- fused MLP forward (csrc/mlpfwd.hip, round 5): timm Mlp + residual + the following LayerNorm in one launch -------------------
  * `x = x + drop_path(mlp(norm2(x)))` then the next norm (deit:76-81; cait:153-157 with colscale = gamma_2):
  *   h = gelu(A W1^T + b1)  bf16 [M][hid]  and  dgelu = gelu'(A W1^T + b1) as 8-bit codes [M][hid]   (both written for backward)

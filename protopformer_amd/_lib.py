@@ -17,6 +17,10 @@ SIGS = {
     "ppf_rowgemm_resid_ln": "pp" "iiiiii" "p" "pp" "pi" "pp" "pp" "ppp" "f" "s",
     "ppf_rowgemm_lnbwd": "pp" "iiiiii" "pppp" "ppp" "pi" "pp" "pz" "s",
     "ppf_rowgemm_colsum": "p" "iii" "ppp" "s",
+    "ppf_layernorm_bwd_f32": "pppppppp" "ii" "f" "s",
+    "ppf_ew_bwd_f32": "i" "ppp" "p" "i" "ii" "s",
+    "ppf_colsum_f32": "pp" "ii" "s",
+    "ppf_attn_bwd_f32": "ppppp" "iiiiii" "s",
     "ppf_mlp_fwd": "ppppp" "iiii" "pp" "pp" "pi" "p" "p" "ppppp" "f" "s",
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",

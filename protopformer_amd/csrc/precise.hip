@@ -1,4 +1,4 @@
-// fp32 VERIFICATION path (PPNet.precise = True / PPF_PRECISE=1): forward-only kernels that keep every operand and every
+// fp32 VERIFICATION path (PPNet.precise = True / PPF_PRECISE=1): kernels (forward; since round 5 a DeiT backward too) that keep every operand and every
 // intermediate in fp32 (exact erf GELU, fp32 FMA contractions through ppf_sgemm), so the whole forward / loss can be held to the
 // north-star tolerance (1e-3 rel) against the reference-generated fixtures, separating "bf16 operand rounding" from "kernel bug".
 // Written for clarity, not speed: it is never on the measured path.
@@ -223,6 +223,145 @@ inline int grid_for(int64_t work) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+
+// ---- fp32 BACKWARD of the verification mode (round 5; DeiT): gradients of the micro fixtures held to 1e-3 of the reference's ----------------
+
+// LayerNorm backward, one wave per row r of dy; x row = row_map ? row_map[r] : r (mean / rstd recomputed from x as the forward did):
+//   dx_out[xrow] = (dres_in ? dres_in[xrow] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dw += dy * xhat, db += dy (atomics)
+__global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ row_map,
+                                                         const float* __restrict__ w, const float* __restrict__ dres_in, float* __restrict__ dx_out,
+                                                         float* __restrict__ dw, float* __restrict__ db, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const size_t xr = (size_t)(row_map ? row_map[r] : r);
+    const float* src = x + xr * D;
+    const float* g = dy + (size_t)r * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += src[c];
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = src[c] - mean; v += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < D; c += 64) { const float xh = (src[c] - mean) * rstd, gg = g[c] * w[c]; s1 += gg; s2 += gg * xh; }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (src[c] - mean) * rstd, gg = g[c] * w[c];
+        dx_out[xr * D + c] = (dres_in ? dres_in[xr * D + c] : 0.f) + rstd * (gg - c1 - xh * c2);
+        atomicAdd(dw + c, g[c] * xh);
+        atomicAdd(db + c, g[c]);
+    }
+}
+
+// elementwise backward pieces on [M][N]: kind 0: out = a * gelu'(b) (exact erf form, b = pre-activation) | 1: out = a * b * (1 - b) (sigmoid, b = its
+// output) | 2: out = a * rowscale[m / rows_per_group] (DropPath factor on a branch gradient; rowscale == NULL: copy)
+__global__ __launch_bounds__(256) void ew_bwd_f32_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                         const float* __restrict__ rowscale, int rows_per_group, int M, int N) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = a[i];
+        if (kind == 0) {
+            const float xv = b[i];
+            v *= 0.5f * (1.0f + erff(xv * 0.70710678118654752440f)) + xv * 0.39894228040143267794f * expf(-0.5f * xv * xv);
+        } else if (kind == 1) v *= b[i] * (1.0f - b[i]);
+        else v *= rowscale ? rowscale[(int)(i / N) / rows_per_group] : 1.0f;
+        out[i] = v;
+    }
+}
+
+// out[n] += sum_m in[m][n]  (bias gradients; one thread per column, rows in order)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += in[(size_t)m * N + n];
+    out[n] += s;
+}
+
+// Backward of attn_f32_kernel: one workgroup per (sample, head).  Phase 1: thread q owns query row q -- probabilities p (the eps form),
+// dP = dO V^T, delta = sum p dP, dS = scale * a * (dP - delta) with a = e keep / Z (d p_j / d s_i = a_i (delta_ij - p_j)), dQ = dS K; p and dS
+// rows go to the scratch [B][H][2][N][N].  Phase 2: thread j owns key row j: dK_j = sum_i dS_ij Q_i, dV_j = sum_i p_ij dO_i.
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ policy,
+                                                           float* __restrict__ dqkv, float* __restrict__ scratch, int H, int N, int D, int self_keep, int eps_n) {
+    extern __shared__ float lds[];
+    const int hd = D / H, b = blockIdx.x / H, h = blockIdx.x % H, t = threadIdx.x;
+    float* tA = lds;                              // K, later Q
+    float* tB = lds + (size_t)N * hd;             // V, later dO
+    const float scale = 1.0f / sqrtf((float)hd), eps = 1e-6f, epsn = eps / (float)(eps_n > 0 ? eps_n : N);
+    const float* base = qkv + (size_t)b * N * 3 * D;
+    const float* dob = dout + (size_t)b * N * D;
+    float* gb = dqkv + (size_t)b * N * 3 * D;
+    const float* pol = policy ? policy + (size_t)b * N : nullptr;
+    float* P = scratch + ((size_t)blockIdx.x * 2) * N * N;
+    float* dS = P + (size_t)N * N;
+    for (int i = t; i < N * hd; i += 256) {
+        const int j = i / hd, d = i % hd;
+        tA[i] = base[(size_t)j * 3 * D + D + h * hd + d];
+        tB[i] = base[(size_t)j * 3 * D + 2 * D + h * hd + d];
+    }
+    __syncthreads();
+    if (t < N) {
+        const int q = t;
+        float qr[64], dor[64], dq[64];
+        for (int d = 0; d < hd; ++d) { qr[d] = base[(size_t)q * 3 * D + h * hd + d]; dor[d] = dob[(size_t)q * D + h * hd + d]; dq[d] = 0.f; }
+        float mx = -INFINITY;
+        for (int j = 0; j < N; ++j) {
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += qr[d] * tA[j * hd + d];
+            mx = fmaxf(mx, s * scale);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < N; ++j) {
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += qr[d] * tA[j * hd + d];
+            float keep = pol ? pol[j] : 1.0f;
+            if (self_keep && j == q) keep = 1.0f;
+            sum += expf(s * scale - mx) * keep;
+        }
+        const float zinv = 1.0f / (sum + eps);
+        float delta = 0.f;
+        for (int j = 0; j < N; ++j) {
+            float s = 0.f, dp = 0.f;
+            for (int d = 0; d < hd; ++d) { s += qr[d] * tA[j * hd + d]; dp += dor[d] * tB[j * hd + d]; }
+            float keep = pol ? pol[j] : 1.0f;
+            if (self_keep && j == q) keep = 1.0f;
+            const float p = (expf(s * scale - mx) * keep + epsn) * zinv;
+            P[(size_t)q * N + j] = p;
+            dS[(size_t)q * N + j] = dp;
+            delta += p * dp;
+        }
+        for (int j = 0; j < N; ++j) {
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += qr[d] * tA[j * hd + d];
+            float keep = pol ? pol[j] : 1.0f;
+            if (self_keep && j == q) keep = 1.0f;
+            const float a = expf(s * scale - mx) * keep * zinv;
+            const float ds = scale * a * (dS[(size_t)q * N + j] - delta);
+            dS[(size_t)q * N + j] = ds;
+            for (int d = 0; d < hd; ++d) dq[d] += ds * tA[j * hd + d];
+        }
+        for (int d = 0; d < hd; ++d) gb[(size_t)q * 3 * D + h * hd + d] = dq[d];
+    }
+    __threadfence();
+    __syncthreads();
+    for (int i = t; i < N * hd; i += 256) {
+        const int j = i / hd, d = i % hd;
+        tA[i] = base[(size_t)j * 3 * D + h * hd + d];             // Q
+        tB[i] = dob[(size_t)j * D + h * hd + d];                  // dO
+    }
+    __syncthreads();
+    if (t < N) {
+        const int j = t;
+        float dk[64], dv[64];
+        for (int d = 0; d < hd; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        for (int i = 0; i < N; ++i) {
+            const float ds = dS[(size_t)i * N + j], p = P[(size_t)i * N + j];
+            for (int d = 0; d < hd; ++d) { dk[d] += ds * tA[i * hd + d]; dv[d] += p * tB[i * hd + d]; }
+        }
+        for (int d = 0; d < hd; ++d) { gb[(size_t)j * 3 * D + D + h * hd + d] = dk[d]; gb[(size_t)j * 3 * D + 2 * D + h * hd + d] = dv[d]; }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +417,44 @@ int ppf_class_attn_fwd_f32(const float* q, const float* k, const float* v, const
     PPF_CHECK_ARG(B > 0 && H > 0 && N1 > 0 && N1 <= 256 && D % H == 0, PPF_ERR_SHAPE, "ppf_class_attn_fwd_f32: bad shape");
     const size_t lds = ((size_t)H * N1 + 256) * sizeof(float);
     hipLaunchKernelGGL(class_attn_f32_kernel, dim3(B), dim3(256), lds, stream, q, k, v, policy, attn_mean, out, H, N1, D);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ---- fp32 backward of the verification mode (DeiT; tests/test_gpu_precise.py holds grad/* of the reference fixtures to 1e-3 with it) ----
+int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
+                          int rows, int D, float eps, hipStream_t stream) {
+    PPF_CHECK_ARG(dy && x && w && dx_out && dw && db && rows > 0 && D > 0, PPF_ERR_ARG, "ppf_layernorm_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dy, x, row_map, w, dres_in, dx_out, dw, db, rows, D, eps);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// kind 0: out = a * gelu'(b) | 1: out = a * b * (1 - b) | 2: out = a * rowscale[m / rows_per_group] (rowscale NULL: copy); out may alias a
+int ppf_ew_bwd_f32(int kind, const float* a, const float* b, float* out, const float* rowscale, int rows_per_group, int M, int N, hipStream_t stream) {
+    PPF_CHECK_ARG(a && out && M > 0 && N > 0 && kind >= 0 && kind <= 2 && (kind == 2 || b), PPF_ERR_ARG, "ppf_ew_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(ew_bwd_f32_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, stream, kind, a, b, out, rowscale, rows_per_group > 0 ? rows_per_group : 1, M, N);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_colsum_f32(const float* in, float* out, int M, int N, hipStream_t stream) {
+    PPF_CHECK_ARG(in && out && M > 0 && N > 0, PPF_ERR_ARG, "ppf_colsum_f32: bad arguments");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, in, out, M, N);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+// dqkv fp32 [B*N][3D] from dout fp32 [B*N][D]; scratch: B*H*2*N*N floats
+int ppf_attn_bwd_f32(const float* qkv, const float* dout, const float* policy, float* dqkv, float* scratch, int B, int H, int N, int D, int self_keep,
+                     int eps_n, hipStream_t stream) {
+    PPF_CHECK_ARG(qkv && dout && dqkv && scratch && B > 0 && H > 0 && N > 0 && N <= 256 && D % H == 0 && D / H <= 64, PPF_ERR_SHAPE,
+                  "ppf_attn_bwd_f32: bad shape B=%d H=%d N=%d D=%d", B, H, N, D);
+    const size_t lds = (size_t)2 * N * (D / H) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd_f32: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(256), lds, stream, qkv, dout, policy, dqkv, scratch, H, N, D, self_keep, eps_n);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -737,3 +737,51 @@ def class_attn_fwd_f32(q, k, v, policy, B, H, N1, D):
     attn_mean = torch.empty((B, N1), dtype=torch.float32, device=q.device)
     _lib.call("ppf_class_attn_fwd_f32", q, k, v, policy, attn_mean, out, B, H, N1, D)
     return out, attn_mean
+
+
+# ------------------------------------------------------------------------------------------------ fp32 verification mode: backward pieces
+def layernorm_bwd_f32(dy, x, w, dw, db, dx_out, dres_in=None, row_map=None, eps=1e-6):
+    """dx_out[xrow] = (dres_in[xrow] or 0) + LN'(dy); dw / db += (fp32 atomics); rows of dy <-> rows row_map[r] of x (None: identity)."""
+    rows, D = dy.shape
+    _lib.call("ppf_layernorm_bwd_f32", dy, x, row_map, w, dres_in, dx_out, dw, db, rows, D, float(eps))
+    return dx_out
+
+
+def ew_bwd_f32(kind, a, b=None, rowscale=None, rows_per_group=1):
+    """kind 0: a * gelu'(b) | 1: a * b * (1 - b) | 2: a * rowscale[row // rows_per_group] (rowscale None: copy)."""
+    M, N = a.shape
+    out = torch.empty_like(a)
+    _lib.call("ppf_ew_bwd_f32", int(kind), a, b, out, rowscale, rows_per_group, M, N)
+    return out
+
+
+def colsum_f32(x, out):
+    """out[n] += sum_m x[m, n]."""
+    M, N = x.shape
+    _lib.call("ppf_colsum_f32", x, out, M, N)
+
+
+def attn_bwd_f32(qkv, dout, B, H, N, D, policy=None, self_keep=True, eps_n=0):
+    dqkv = torch.empty_like(qkv)
+    scratch = torch.empty(B * H * 2 * N * N, dtype=torch.float32, device=qkv.device)
+    _lib.call("ppf_attn_bwd_f32", qkv, dout, policy, dqkv, scratch, B, H, N, D, int(self_keep), int(eps_n))
+    return dqkv
+
+
+def linear_dgrad_f32(dy, w):
+    """dx [M, K] = dy [M, N] @ w [N, K] through ppf_sgemm (fp32 FMA)."""
+    M, N = dy.shape
+    w2 = w.reshape(N, -1)
+    K = w2.shape[1]
+    out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    return sgemm(dy, w2, out, M, K, N, N, 1, 1, K)
+
+
+def linear_wgrad_f32(dy, x, gw, gb=None):
+    """gw [N, K] += dy [M, N]^T @ x [M, K] (and gb [N] += column sums of dy) through ppf_sgemm, accumulating into the flat gradient views."""
+    M, N = dy.shape
+    K = x.shape[1]
+    sgemm(dy, x, gw.reshape(N, K), N, K, M, 1, N, 1, K, alpha=1.0, beta=1.0)
+    if gb is not None:
+        colsum_f32(dy, gb)
+

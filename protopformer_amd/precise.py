@@ -1,11 +1,13 @@
-"""fp32 verification mode of the backbone (forward only): the same call sequence as backbone.py / cait.py with every operand and
+"""fp32 verification mode of the backbone (DeiT: forward and backward; CaiT: forward only): the same call sequence as backbone.py / cait.py with every operand and
 intermediate in fp32 (csrc/precise.hip + ppf_sgemm), the masked full-length blocks of the reference after the token reservation
-(no compaction), fp32 master weights.  Enabled by ``PPNet.precise = True`` or ``PPF_PRECISE=1`` under ``torch.no_grad()``.
+(no compaction), fp32 master weights.  Enabled by ``PPNet.precise = True`` or ``PPF_PRECISE=1``; with gradients enabled the DeiT
+path records what its fp32 backward needs (``PreciseTokensFn``), CaiT must run under ``torch.no_grad()``.
 
 Purpose: the bf16 product path carries ~4e-3 of operand rounding per GEMM, so end to end it can only be gated at a few 1e-3; this
 mode holds the *whole* forward / loss to the north-star 1e-3 rel against the reference-generated fixtures
 (tests/test_gpu_precise.py), which separates "bf16 rounding" from "kernel / orchestration bug" (rollout, reservation, prototype
-layer, PPC and CE kernels are shared with the product path).  It is never on the measured path.
+layer, PPC and CE kernels are shared with the product path).  The DeiT backward does the same for the gradients: every weight
+gradient of the reference fixture is held at 1e-3 where the bf16 step can only be gated on its direction.  Never on the measured path.
 Reference lines: deit:172-240, cait:303-345, protopformer.py:141-173."""
 import torch
 
@@ -39,16 +41,20 @@ def _head(ppnet, x, idx):
     return f.reshape(B, 1 + k, conv.out_channels)
 
 
-def deit_tokens(ppnet, img, dp):
+def deit_tokens(ppnet, img, dp, saved=None):
     feats = ppnet.features
     (layer, k), = ppnet.reserve_layer_nums
-    x = _embed(feats, img, 1)
+    pe = feats.patch_embed
+    cols = ops.im2col_patch_f32(img.contiguous().float(), pe.patch_size)
+    tok = ops.linear_f32(cols, pe.proj.weight, pe.proj.bias)
+    x = ops.assemble_tokens(tok, feats.cls_token, feats.pos_embed, img.shape[0], pe.num_patches, feats.embed_dim, 1)
     B, N, D = x.shape
     H = feats.num_heads
     NP = (N + 3) // 4 * 4
     hm = torch.empty((max(layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
     x = x.reshape(B * N, D)
     policy = cls_attn = idx = None
+    layers = []
     for i, blk in enumerate(feats.blocks):
         if i == layer:
             cls_attn, idx, policy = ops.rollout(hm, layer, B, N, k, lead=1)
@@ -56,8 +62,84 @@ def deit_tokens(ppnet, img, dp):
         qkv = ops.linear_f32(n1, blk.attn.qkv.weight, blk.attn.qkv.bias)
         ao = ops.attn_fwd_f32(qkv, B, H, N, D, policy=policy, self_keep=True, headmean=hm[i] if i < layer else None)
         x1 = ops.linear_f32(ao, blk.attn.proj.weight, blk.attn.proj.bias, kind=3, res=x, rowscale=_dp(dp, 2 * i), rows_per_group=N)
+        layers.append((x, qkv, ao, x1, policy))
         x = _mlp(blk, x1, N, _dp(dp, 2 * i + 1))
-    return _head(ppnet, x.reshape(B, N, D), idx), cls_attn, idx
+    rows = ops.reserved_rows_map(idx, N)
+    nf = ops.layernorm_fwd_f32(x, feats.norm.weight, feats.norm.bias, LN_EPS, row_map=rows)          # deit:238 on the reserved rows
+    conv = ppnet.add_on_layers[0]
+    f = ops.linear_f32(nf, conv.weight, conv.bias, kind=2)                                          # protopformer.py:162-172
+    if saved is not None:
+        saved.update(cols=cols, layers=layers, x_last=x, rows=rows, nf=nf, f=f, shape=(B, N, D), dp=dp)
+    return f.reshape(B, 1 + k, conv.out_channels), cls_attn, idx
+
+
+def _gv(store, p):
+    return store.grad_view(p) if p is not None and p.requires_grad else None
+
+
+def _linear_bwd(store, dy, x, lin, want_dx=True):
+    """gradients of y = x W^T + b: W.grad += dy^T x, b.grad += colsum(dy) (into the flat store's views); returns dy W."""
+    gw = _gv(store, lin.weight)
+    if gw is not None:
+        ops.linear_wgrad_f32(dy, x, gw, _gv(store, lin.bias))
+    return ops.linear_dgrad_f32(dy, lin.weight) if want_dx else None
+
+
+def deit_backward_f32(ppnet, saved, df):
+    """fp32 backward of deit_tokens (deit:172-240 + the add-on head): every product through ppf_sgemm, the elementwise / LayerNorm /
+    attention pieces through csrc/precise.hip; gradients ACCUMULATE into the flat store's views (p.grad), as autograd's would."""
+    store = ppnet.flat_store()
+    store.attach_all_grads()
+    feats = ppnet.features
+    B, N, D = saved["shape"]
+    H, dp = feats.num_heads, saved["dp"]
+    dz = ops.ew_bwd_f32(1, df, saved["f"])                                                          # sigmoid'
+    dnf = _linear_bwd(store, dz, saved["nf"], ppnet.add_on_layers[0])
+    dx = ops.zeros((B * N, D), torch.float32, df.device)                                            # rows outside the reservation stay zero
+    ops.layernorm_bwd_f32(dnf, saved["x_last"], feats.norm.weight, _gv(store, feats.norm.weight), _gv(store, feats.norm.bias), dx,
+                          row_map=saved["rows"], eps=LN_EPS)
+    for i in reversed(range(len(feats.blocks))):
+        blk = feats.blocks[i]
+        x_in, qkv, ao, x1, policy = saved["layers"][i]
+        # x_out = x1 + s2 * fc2(gelu(fc1(norm2(x1))))
+        dyb = ops.ew_bwd_f32(2, dx, rowscale=_dp(dp, 2 * i + 1), rows_per_group=N)
+        n2 = ops.layernorm_fwd_f32(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
+        pre = ops.linear_f32(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+        h = ops.linear_f32(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, kind=1)
+        dh = _linear_bwd(store, dyb, h, blk.mlp.fc2)
+        dpre = ops.ew_bwd_f32(0, dh, pre)                                                           # gelu'
+        dn2 = _linear_bwd(store, dpre, n2, blk.mlp.fc1)
+        ops.layernorm_bwd_f32(dn2, x1, blk.norm2.weight, _gv(store, blk.norm2.weight), _gv(store, blk.norm2.bias), dx, dres_in=dx, eps=LN_EPS)
+        # x1 = x + s1 * proj(attention(qkv(norm1(x))))
+        dyb = ops.ew_bwd_f32(2, dx, rowscale=_dp(dp, 2 * i), rows_per_group=N)
+        dao = _linear_bwd(store, dyb, ao, blk.attn.proj)
+        dqkv = ops.attn_bwd_f32(qkv, dao, B, H, N, D, policy=policy, self_keep=True)
+        n1 = ops.layernorm_fwd_f32(x_in, blk.norm1.weight, blk.norm1.bias, LN_EPS)
+        dn1 = _linear_bwd(store, dqkv, n1, blk.attn.qkv)
+        ops.layernorm_bwd_f32(dn1, x_in, blk.norm1.weight, _gv(store, blk.norm1.weight), _gv(store, blk.norm1.bias), dx, dres_in=dx, eps=LN_EPS)
+    pe = feats.patch_embed
+    Np = pe.num_patches
+    ops.assemble_tokens_bwd(dx, _gv(store, feats.pos_embed), _gv(store, feats.cls_token), B, Np, D, 1)       # dpos / dcls (fp32, fixed order)
+    dtok = dx.reshape(B, N, D)[:, 1:].reshape(B * Np, D).contiguous()
+    _linear_bwd(store, dtok, saved["cols"], pe.proj, want_dx=False)
+
+
+class PreciseTokensFn(torch.autograd.Function):
+    """image -> (f, cls_token_attn, reserve idx) in fp32 with an fp32 backward (DeiT); parameters enter only to hook autograd."""
+
+    @staticmethod
+    def forward(ctx, img, ppnet, dp, *params):
+        saved = {} if any(ctx.needs_input_grad) else None
+        f, cls_attn, idx = deit_tokens(ppnet, img, dp, saved)
+        ctx.saved, ctx.ppnet = saved, ppnet
+        ctx.mark_non_differentiable(cls_attn, idx)
+        return f, cls_attn, idx
+
+    @staticmethod
+    def backward(ctx, df, _dcls, _didx):
+        deit_backward_f32(ctx.ppnet, ctx.saved, df.contiguous().reshape(-1, df.shape[-1]).float())
+        ctx.saved = None
+        return (None,) * len(ctx.needs_input_grad)
 
 
 def cait_tokens(ppnet, img, dp):
@@ -101,7 +183,9 @@ def cait_tokens(ppnet, img, dp):
 
 def tokens(ppnet, img, dp):
     from .deit import MyVisionTransformer
+    deit = isinstance(ppnet.features, MyVisionTransformer)
     if torch.is_grad_enabled() and any(p.requires_grad for p in ppnet.parameters()):
-        raise RuntimeError("the fp32 verification mode (PPNet.precise / PPF_PRECISE=1) is forward-only: call it under torch.no_grad()")
-    fn = deit_tokens if isinstance(ppnet.features, MyVisionTransformer) else cait_tokens
-    return fn(ppnet, img, dp)
+        if not deit:
+            raise RuntimeError("the fp32 verification mode (PPNet.precise / PPF_PRECISE=1) is forward-only for CaiT: call it under torch.no_grad()")
+        return PreciseTokensFn.apply(img, ppnet, dp, *ppnet._hook_params())
+    return (deit_tokens if deit else cait_tokens)(ppnet, img, dp)
