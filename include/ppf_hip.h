@@ -89,7 +89,7 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
 
 /* ---- fp32 verification mode, backward (csrc/precise.hip, round 5; DeiT): never on the measured path -----------------------------
  * LayerNorm backward with the statistics recomputed from x (rows of dy <-> rows row_map[r] of x, dx_out written at the x rows, dw / db by
- * fp32 atomics); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale); column sums; Attention backward with the
+ * fp32 atomics); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale, 3 product, 4 row scale x LayerScale column); column sums; Attention backward with the
  * policy softmax of deit:29-43 (scratch: B*H*2*N*N floats). */
 int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
                           int rows, int D, float eps, ppf_stream_t stream);
@@ -97,6 +97,11 @@ int ppf_ew_bwd_f32(int kind, const float* a, const float* b, float* out, const f
 int ppf_colsum_f32(const float* in, float* out, int M, int N, ppf_stream_t stream);
 int ppf_attn_bwd_f32(const float* qkv, const float* dout, const float* policy, float* dqkv, float* scratch, int B, int H, int N, int D, int self_keep,
                      int eps_n, ppf_stream_t stream);
+/* CaiT: TalkingHeadAttn backward (cait:115-132; dqkv zero-filled by the caller, mixer gradients accumulate) and ClassAttn backward (cait:50-90) */
+int ppf_th_attn_bwd_f32(const float* qkv, const float* dout, const float* wl, const float* bl, const float* ww, const float* bw, float* dqkv,
+                        float* dwl, float* dbl, float* dww, float* dbw, int B, int H, int N, int D, ppf_stream_t stream);
+int ppf_class_attn_bwd_f32(const float* q, const float* k, const float* v, const float* policy, const float* dout, float* dq, float* dk, float* dv,
+                           int B, int H, int N1, int D, ppf_stream_t stream);
 
 /* ---- fused MLP forward (csrc/mlpfwd.hip, round 5): timm Mlp + residual + the following LayerNorm in one launch -------------------
  * `x = x + drop_path(mlp(norm2(x)))` then the next norm (deit:76-81; cait:153-157 with colscale = gamma_2):

@@ -21,6 +21,8 @@ SIGS = {
     "ppf_ew_bwd_f32": "i" "ppp" "p" "i" "ii" "s",
     "ppf_colsum_f32": "pp" "ii" "s",
     "ppf_attn_bwd_f32": "ppppp" "iiiiii" "s",
+    "ppf_th_attn_bwd_f32": "ppppppp" "pppp" "iiii" "s",
+    "ppf_class_attn_bwd_f32": "pppppppp" "iiii" "s",
     "ppf_mlp_fwd": "ppppp" "iiii" "pp" "pp" "pi" "p" "p" "ppppp" "f" "s",
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",

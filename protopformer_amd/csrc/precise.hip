@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
 }
 
 // elementwise backward pieces on [M][N]: kind 0: out = a * gelu'(b) (exact erf form, b = pre-activation) | 1: out = a * b * (1 - b) (sigmoid, b = its
-// output) | 2: out = a * rowscale[m / rows_per_group] (DropPath factor on a branch gradient; rowscale == NULL: copy)
+// output) | 2: out = a * rowscale[m / rows_per_group] (DropPath factor on a branch gradient; rowscale == NULL: copy) | 3: out = a * b |
+// 4: out = a * rowscale[m / rows_per_group] * b[n] (b = a LayerScale vector [N])
 __global__ __launch_bounds__(256) void ew_bwd_f32_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                          const float* __restrict__ rowscale, int rows_per_group, int M, int N) {
     const int64_t total = (int64_t)M * N;
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(256) void ew_bwd_f32_kernel(int kind, const float* 
             const float xv = b[i];
             v *= 0.5f * (1.0f + erff(xv * 0.70710678118654752440f)) + xv * 0.39894228040143267794f * expf(-0.5f * xv * xv);
         } else if (kind == 1) v *= b[i] * (1.0f - b[i]);
-        else v *= rowscale ? rowscale[(int)(i / N) / rows_per_group] : 1.0f;
+        else if (kind == 2) v *= rowscale ? rowscale[(int)(i / N) / rows_per_group] : 1.0f;
+        else if (kind == 3) v *= b[i];
+        else v *= (rowscale ? rowscale[(int)(i / N) / rows_per_group] : 1.0f) * b[i % N];
         out[i] = v;
     }
 }
@@ -422,6 +425,164 @@ int ppf_class_attn_fwd_f32(const float* q, const float* k, const float* v, const
 }
 
 
+// block-wide sum over 256 threads through red[256] (every thread calls; returns the total to all)
+__device__ inline float block_sum256(float v, float* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ inline float block_max256(float v, float* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// Backward of th_attn_f32_kernel (cait:115-132): one workgroup per (sample, query), thread j = key.  With S = (q scale) K^T, M = wl S + bl,
+// P = softmax_j M, A = ww P + bw, out = A V:   dA = dO V^T, dV += A^T dO, dww += dA P^T, dbw += sum dA, dP = ww^T dA,
+// dM = P (dP - sum_j P dP), dwl += dM S^T, dbl += sum dM, dS = wl^T dM, dQ = scale dS K, dK += dS^T (q scale).
+// dK / dV (dqkv zero-filled by the caller) and the four mixer gradients are accumulated with fp32 atomics (verification only).
+// lds: qrow [D] | S [H][N] | P [H][N] | T [H][N] (dS) | red [256] | acc [2 H H + 2 H]
+__global__ __launch_bounds__(256) void th_attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ wl,
+                                                              const float* __restrict__ bl, const float* __restrict__ ww, const float* __restrict__ bw,
+                                                              float* __restrict__ dqkv, float* __restrict__ dwl, float* __restrict__ dbl,
+                                                              float* __restrict__ dww, float* __restrict__ dbw, int H, int N, int D) {
+    extern __shared__ float lds[];
+    const int hd = D / H, b = blockIdx.x / N, q = blockIdx.x % N, j = threadIdx.x;
+    float* qrow = lds;
+    float* S = qrow + D;
+    float* P = S + (size_t)H * N;
+    float* T = P + (size_t)H * N;
+    float* red = T + (size_t)H * N;
+    float* acc = red + 256;                       // dwl [H][H] | dww [H][H] | dbl [H] | dbw [H]
+    const int nacc = 2 * H * H + 2 * H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float* base = qkv + (size_t)b * N * 3 * D;
+    const float* dor = dout + ((size_t)b * N + q) * D;
+    float* gb = dqkv + (size_t)b * N * 3 * D;
+    for (int d = threadIdx.x; d < D; d += 256) qrow[d] = base[(size_t)q * 3 * D + d] * scale;
+    for (int i = threadIdx.x; i < nacc; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    if (j < N)
+        for (int h = 0; h < H; ++h) {
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += qrow[h * hd + d] * base[(size_t)j * 3 * D + D + h * hd + d];
+            S[h * N + j] = s;
+        }
+    __syncthreads();
+    for (int g = 0; g < H; ++g) {
+        float m = -INFINITY;
+        if (j < N) {
+            m = bl[g];
+            for (int h = 0; h < H; ++h) m += wl[g * H + h] * S[h * N + j];
+        }
+        const float mx = block_max256(m, red);
+        const float e = j < N ? expf(m - mx) : 0.f;
+        const float sum = block_sum256(e, red);
+        if (j < N) P[g * N + j] = e / sum;
+    }
+    __syncthreads();
+    float dA[16], dP[16], dM[16];
+    for (int g = 0; g < H; ++g) { dA[g] = 0.f; dP[g] = 0.f; dM[g] = 0.f; }
+    if (j < N) {
+        for (int g = 0; g < H; ++g) {
+            float a = bw[g], da = 0.f;
+            for (int h = 0; h < H; ++h) a += ww[g * H + h] * P[h * N + j];
+            for (int d = 0; d < hd; ++d) {
+                const float o = dor[g * hd + d];
+                da += o * base[(size_t)j * 3 * D + 2 * D + g * hd + d];
+                atomicAdd(gb + (size_t)j * 3 * D + 2 * D + g * hd + d, a * o);                     // dV
+            }
+            dA[g] = da;
+            atomicAdd(acc + 2 * H * H + H + g, da);                                                // dbw
+            for (int h = 0; h < H; ++h) atomicAdd(acc + H * H + g * H + h, da * P[h * N + j]);     // dww
+        }
+        for (int h = 0; h < H; ++h) {
+            float v = 0.f;
+            for (int g = 0; g < H; ++g) v += ww[g * H + h] * dA[g];
+            dP[h] = v;
+        }
+    }
+    for (int g = 0; g < H; ++g) {
+        const float dot = block_sum256(j < N ? P[g * N + j] * dP[g] : 0.f, red);
+        if (j < N) dM[g] = P[g * N + j] * (dP[g] - dot);
+    }
+    if (j < N) {
+        for (int g = 0; g < H; ++g) {
+            atomicAdd(acc + 2 * H * H + g, dM[g]);                                                  // dbl
+            for (int h = 0; h < H; ++h) atomicAdd(acc + g * H + h, dM[g] * S[h * N + j]);          // dwl
+        }
+        for (int h = 0; h < H; ++h) {
+            float ds = 0.f;
+            for (int g = 0; g < H; ++g) ds += wl[g * H + h] * dM[g];
+            T[h * N + j] = ds;
+            for (int d = 0; d < hd; ++d) atomicAdd(gb + (size_t)j * 3 * D + D + h * hd + d, ds * qrow[h * hd + d]);      // dK
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const int h = c / hd;
+        float a = 0.f;
+        for (int k = 0; k < N; ++k) a += T[h * N + k] * base[(size_t)k * 3 * D + D + c];
+        gb[(size_t)q * 3 * D + c] = a * scale;                                                      // dQ (single writer)
+    }
+    for (int i = threadIdx.x; i < nacc; i += 256) {
+        float* dst = i < H * H ? dwl + i : i < 2 * H * H ? dww + (i - H * H) : i < 2 * H * H + H ? dbl + (i - 2 * H * H) : dbw + (i - 2 * H * H - H);
+        atomicAdd(dst, acc[i]);
+    }
+}
+
+// Backward of class_attn_f32_kernel (cait:50-90): one workgroup per sample, thread j = key; dq [B][D], dk / dv [B*N1][D] (single writers).
+// lds: dS [H][N1] | red [256]
+__global__ __launch_bounds__(256) void class_attn_bwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                 const float* __restrict__ policy, const float* __restrict__ dout,
+                                                                 float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                                 int H, int N1, int D) {
+    extern __shared__ float lds[];
+    const int hd = D / H, b = blockIdx.x, j = threadIdx.x;
+    float* dS = lds;
+    float* red = dS + (size_t)H * N1;
+    const float scale = 1.0f / sqrtf((float)hd), eps = 1e-6f;
+    for (int h = 0; h < H; ++h) {
+        float s = -INFINITY;
+        if (j < N1) {
+            s = 0.f;
+            for (int d = 0; d < hd; ++d) s += q[(size_t)b * D + h * hd + d] * scale * k[((size_t)b * N1 + j) * D + h * hd + d];
+        }
+        const float mx = block_max256(s, red);
+        const float e = j < N1 ? expf(s - mx) * (policy ? policy[(size_t)b * N1 + j] : 1.0f) : 0.f;
+        const float sum = block_sum256(e, red);
+        float p = 0.f, dp = 0.f;
+        if (j < N1) {
+            p = (e + eps / (float)N1) / (sum + eps);
+            for (int d = 0; d < hd; ++d) {
+                const float o = dout[(size_t)b * D + h * hd + d];
+                dp += o * v[((size_t)b * N1 + j) * D + h * hd + d];
+                dv[((size_t)b * N1 + j) * D + h * hd + d] = p * o;
+            }
+        }
+        const float delta = block_sum256(p * dp, red);
+        if (j < N1) {
+            const float ds = e / (sum + eps) * (dp - delta);
+            dS[h * N1 + j] = ds;
+            for (int d = 0; d < hd; ++d) dk[((size_t)b * N1 + j) * D + h * hd + d] = ds * scale * q[(size_t)b * D + h * hd + d];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const int h = c / hd;
+        float a = 0.f;
+        for (int t = 0; t < N1; ++t) a += dS[h * N1 + t] * k[((size_t)b * N1 + t) * D + c];
+        dq[(size_t)b * D + c] = a * scale;
+    }
+}
+
+
 // ---- fp32 backward of the verification mode (DeiT; tests/test_gpu_precise.py holds grad/* of the reference fixtures to 1e-3 with it) ----
 int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
                           int rows, int D, float eps, hipStream_t stream) {
@@ -431,9 +592,10 @@ int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, c
     return 0;
 }
 
-// kind 0: out = a * gelu'(b) | 1: out = a * b * (1 - b) | 2: out = a * rowscale[m / rows_per_group] (rowscale NULL: copy); out may alias a
+// kind 0: out = a * gelu'(b) | 1: out = a * b * (1 - b) | 2: out = a * rowscale[m / rows_per_group] (rowscale NULL: copy) | 3: out = a * b |
+// 4: out = a * rowscale[..] * b[n] (LayerScale column vector); out may alias a
 int ppf_ew_bwd_f32(int kind, const float* a, const float* b, float* out, const float* rowscale, int rows_per_group, int M, int N, hipStream_t stream) {
-    PPF_CHECK_ARG(a && out && M > 0 && N > 0 && kind >= 0 && kind <= 2 && (kind == 2 || b), PPF_ERR_ARG, "ppf_ew_bwd_f32: bad arguments");
+    PPF_CHECK_ARG(a && out && M > 0 && N > 0 && kind >= 0 && kind <= 4 && (kind == 2 || b), PPF_ERR_ARG, "ppf_ew_bwd_f32: bad arguments");
     hipLaunchKernelGGL(ew_bwd_f32_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, stream, kind, a, b, out, rowscale, rows_per_group > 0 ? rows_per_group : 1, M, N);
     PPF_LAUNCH_CHECK();
     return 0;
@@ -455,6 +617,30 @@ int ppf_attn_bwd_f32(const float* qkv, const float* dout, const float* policy, f
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { ppf_set_error("ppf_attn_bwd_f32: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(256), lds, stream, qkv, dout, policy, dqkv, scratch, H, N, D, self_keep, eps_n);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// dqkv [B*N][3D] must be ZERO-FILLED by the caller (dK / dV accumulate); dwl / dww [H][H], dbl / dbw [H] accumulate (fp32 atomics)
+int ppf_th_attn_bwd_f32(const float* qkv, const float* dout, const float* wl, const float* bl, const float* ww, const float* bw, float* dqkv,
+                        float* dwl, float* dbl, float* dww, float* dbw, int B, int H, int N, int D, hipStream_t stream) {
+    PPF_CHECK_ARG(qkv && dout && wl && bl && ww && bw && dqkv && dwl && dbl && dww && dbw && B > 0 && H > 0 && H <= 16 && N > 0 && N <= 256 && D % H == 0,
+                  PPF_ERR_SHAPE, "ppf_th_attn_bwd_f32: bad shape B=%d H=%d N=%d D=%d", B, H, N, D);
+    const size_t lds = ((size_t)D + 3 * (size_t)H * N + 256 + 2 * H * H + 2 * H) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)th_attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { ppf_set_error("ppf_th_attn_bwd_f32: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(th_attn_bwd_f32_kernel, dim3(B * N), dim3(256), lds, stream, qkv, dout, wl, bl, ww, bw, dqkv, dwl, dbl, dww, dbw, H, N, D);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_class_attn_bwd_f32(const float* q, const float* k, const float* v, const float* policy, const float* dout, float* dq, float* dk, float* dv,
+                           int B, int H, int N1, int D, hipStream_t stream) {
+    PPF_CHECK_ARG(q && k && v && dout && dq && dk && dv && B > 0 && H > 0 && N1 > 0 && N1 <= 256 && D % H == 0, PPF_ERR_SHAPE,
+                  "ppf_class_attn_bwd_f32: bad shape");
+    const size_t lds = ((size_t)H * N1 + 256) * sizeof(float);
+    hipLaunchKernelGGL(class_attn_bwd_f32_kernel, dim3(B), dim3(256), lds, stream, q, k, v, policy, dout, dq, dk, dv, H, N1, D);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -748,7 +748,8 @@ def layernorm_bwd_f32(dy, x, w, dw, db, dx_out, dres_in=None, row_map=None, eps=
 
 
 def ew_bwd_f32(kind, a, b=None, rowscale=None, rows_per_group=1):
-    """kind 0: a * gelu'(b) | 1: a * b * (1 - b) | 2: a * rowscale[row // rows_per_group] (rowscale None: copy)."""
+    """kind 0: a * gelu'(b) | 1: a * b * (1 - b) | 2: a * rowscale[row // rows_per_group] (rowscale None: copy) | 3: a * b |
+    4: a * rowscale[..] * b[col] (b a LayerScale vector)."""
     M, N = a.shape
     out = torch.empty_like(a)
     _lib.call("ppf_ew_bwd_f32", int(kind), a, b, out, rowscale, rows_per_group, M, N)
@@ -784,4 +785,17 @@ def linear_wgrad_f32(dy, x, gw, gb=None):
     sgemm(dy, x, gw.reshape(N, K), N, K, M, 1, N, 1, K, alpha=1.0, beta=1.0)
     if gb is not None:
         colsum_f32(dy, gb)
+
+
+def th_attn_bwd_f32(qkv, dout, mix, gmix, B, H, N, D):
+    """mix = (wl, bl, ww, bw) of the talking-heads mixers, gmix their gradient views (accumulated)."""
+    dqkv = zeros(qkv.shape, torch.float32, qkv.device)
+    _lib.call("ppf_th_attn_bwd_f32", qkv, dout, mix[0], mix[1], mix[2], mix[3], dqkv, gmix[0], gmix[1], gmix[2], gmix[3], B, H, N, D)
+    return dqkv
+
+
+def class_attn_bwd_f32(q, k, v, policy, dout, B, H, N1, D):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _lib.call("ppf_class_attn_bwd_f32", q, k, v, policy, dout, dq, dk, dv, B, H, N1, D)
+    return dq, dk, dv
 

@@ -51,23 +51,15 @@ def test_precise_forward_and_loss_match_reference_fixture(name):
             assert rel_err(val, z[f"train/{nm}"]) < TOL, (nm, float(val), float(z[f"train/{nm}"]))
 
 
-def test_precise_mode_is_forward_only_for_cait():
-    sd, cfg, z = micro("micro_cait.npz")
-    m = build_micro(cfg, sd)
-    m.precise = True
-    m.train()
-    with pytest.raises(RuntimeError, match="forward-only"):
-        m(torch.from_numpy(z["img"]).cuda())
-
-
-def test_precise_backward_matches_reference_gradients():
-    """fp32 forward + fp32 backward of the DeiT micro model against grad/* of the reference-generated fixture (autograd of the
+@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz"])
+def test_precise_backward_matches_reference_gradients(name):
+    """fp32 forward + fp32 backward of the DeiT / CaiT micro models against grad/* of the reference-generated fixture (autograd of the
     reference itself): EVERY parameter gradient within 1e-3 of its tensor's scale, element by element.  The bf16 step of the product
     path is gated on gradient direction (cosine, test_gpu_e2e.py); this holds the orchestration of the backward -- LayerNorm / GELU /
-    policy-softmax derivatives, the residual and DropPath routing, the reserved-row scatter, the prototype / PPC / CE gradients that
+    policy-softmax / talking-heads / class-attention / LayerScale derivatives, the residual and DropPath routing, the reserved-row scatter, the prototype / PPC / CE gradients that
     the product path shares -- to the north-star tolerance."""
     from protopformer_amd.protopformer import CrossEntropyLoss
-    sd, cfg, z = micro("micro_deit.npz")
+    sd, cfg, z = micro(name)
     m = build_micro(cfg, sd)
     m.precise = True
     m.train()
