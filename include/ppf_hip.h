@@ -250,8 +250,11 @@ int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, ppf_stre
 int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
                   float eps, float* act_max, int* argmax, float* dist_full, float* act_full, ppf_stream_t stream);
 int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
-                  float eps, const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok,
+                  float eps, const float* dist_full, int map_is_act, const float* g_full, const float* g_max, const int* argmax, float* dtok,
                   int64_t dstride_b, float* dprotos, void* zeroed_workspace, size_t workspace_bytes, ppf_stream_t stream);
+/* map_is_act != 0: the [B][P][T] map passed as dist_full holds the ACTIVATIONS ppf_proto_fwd wrote (act_full), not the distances; the
+ * derivative is then taken from them (a = log((d+1)/(d+eps)) => da/dd = -(e^a - 1)^2 / ((1 - eps) e^a), 0 at the clipped d == 0), so a
+ * training forward writes one (B,P,T) map instead of two. */
 /* workspace: ppf_proto_bwd_workspace() bytes = [bitmap of the non-zero dL/dd entries, B*T*ceil(P/32)*4 bytes rounded up to 256, present
  * and ZERO-FILLED by the caller when dtok != NULL][scratch of the prototype gradients when dprotos != NULL, any content].  A workspace
  * that only holds the bitmap is accepted: the prototype gradients then take the per-prototype gather kernel (same results to rounding). */
@@ -260,7 +263,7 @@ size_t ppf_proto_bwd_workspace(int B, int T, int P, int Dp, int want_dtok, int w
  * prototypes of the sample's own class get a gradient): g_rows [B][ppc][T] = dL/d act_full[b][label[b]*ppc + k][t]; every other entry
  * of the (B,P,T) gradient is zero and is never materialised.  label_i64: int64 labels [B] (0 <= label*ppc <= P - ppc). */
 int ppf_proto_bwd_rows(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
-                       float eps, const float* dist_full, const float* g_rows, const void* label_i64, int ppc, const float* g_max,
+                       float eps, const float* dist_full, int map_is_act, const float* g_rows, const void* label_i64, int ppc, const float* g_max,
                        const int* argmax, float* dtok, int64_t dstride_b, float* dprotos, void* workspace, size_t workspace_bytes,
                        ppf_stream_t stream);
 /* T == 1 (global branch, protopformer.py:295,311 and its autograd): dense form of the same backward -- two fp32 products instead of the

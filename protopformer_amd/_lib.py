@@ -46,8 +46,8 @@ SIGS = {
     "ppf_rollout_compact_layer": "p" "iiii" "f" "p" "s",
     "ppf_rollout_compact": "p" "iii" "p" "iiii" "f" "i" "ppp" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
-    "ppf_proto_bwd": "pliip" "iiii" "f" "ppppp" "l" "p" "pz" "s",
-    "ppf_proto_bwd_rows": "pliip" "iiii" "f" "ppp" "i" "ppp" "l" "p" "pz" "s",
+    "ppf_proto_bwd": "pliip" "iiii" "f" "pi" "pppp" "l" "p" "pz" "s",
+    "ppf_proto_bwd_rows": "pliip" "iiii" "f" "pi" "pp" "i" "ppp" "l" "p" "pz" "s",
     "ppf_proto_bwd_single": "plip" "iiii" "f" "ppp" "l" "p" "pz" "s",
     "ppf_ppc_loss": "ppp" "iiiii" "ff" "pppp" "s",
     "ppf_ppc_loss_bwd": "pppppp" "iiii" "s",

@@ -356,7 +356,8 @@ struct ProtoBwdParams {
     const float* tok; int64_t stride_b; int t0, T;
     const float* protos; int B, P, Dp;
     int act_kind; float eps;
-    const float* dist_full;    // [B][P][T]
+    const float* dist_full;    // [B][P][T]: the distances (map_is_act == 0) or the ACTIVATIONS the forward wrote (map_is_act == 1)
+    int map_is_act;
     const float* g_full;       // [B][P][T] upstream grad of act_full, or null
     const float* g_rows;       // [B][ppc][T] or null: the same gradient in block form -- sample b's rows are the prototypes
     const long long* row_label;//   row_label[b]*ppc ... +ppc-1 (the PPC loss touches nothing else); added to g_full when both are given
@@ -373,6 +374,17 @@ __device__ __forceinline__ float dact_dd(float d, int kind, float eps) {
     return kind == 0 ? (1.0f / (d + 1.0f) - 1.0f / (d + eps)) : -1.0f;
 }
 
+// The same derivative from the ACTIVATION a the forward wrote (training keeps only that map): with E = e^a = (d+1)/(d+eps),
+// d + eps = (1-eps)/(E-1) and d + 1 = E (1-eps)/(E-1), so da/dd = -(E-1)^2 / ((1-eps) E); the clipped branch d == 0 is the forward's own
+// value at d = 0 (same instruction sequence, bit-equal).  Relative error of the result ~ 2 ulp(a) E/(E-1): 1e-6 over the whole range.
+__device__ __forceinline__ float dact_from_act(float a, int kind, float eps) {
+    if (kind != 0) return a < 0.f ? -1.0f : 0.f;
+    if (a >= activation(0.f, 0, eps)) return 0.f;
+    const float em1 = expm1f(a);
+    return -(em1 * em1) / ((1.0f - eps) * (em1 + 1.0f));
+}
+__device__ __forceinline__ float dact_map(const ProtoBwdParams& p, size_t o);
+
 // G[b,p,t] = dL/dd
 __device__ __forceinline__ float grad_d(const ProtoBwdParams& p, int b, int pi, int t, int amax, float gmax) {
     const size_t o = ((size_t)b * p.P + pi) * p.T + t;
@@ -383,7 +395,11 @@ __device__ __forceinline__ float grad_d(const ProtoBwdParams& p, int b, int pi, 
     }
     if (t == amax) g += gmax;
     if (g == 0.f) return 0.f;
-    return g * dact_dd(p.dist_full[o], p.act_kind, p.eps);
+    return g * dact_map(p, o);
+}
+__device__ __forceinline__ float dact_map(const ProtoBwdParams& p, size_t o) {
+    const float v = p.dist_full[o];
+    return p.map_is_act ? dact_from_act(v, p.act_kind, p.eps) : dact_dd(v, p.act_kind, p.eps);
 }
 
 // Token gradients in two fully parallel passes (deterministic, no float atomics):
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_kernel(const ProtoBwdPa
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 float G = 0.f;
-                if (g[u] != 0.f) G = g[u] * dact_dd(p.dist_full[(size_t)bb[u] * PT + (size_t)pi * p.T + tt[u]], p.act_kind, p.eps);
+                if (g[u] != 0.f) G = g[u] * dact_map(p, (size_t)bb[u] * PT + (size_t)pi * p.T + tt[u]);
                 const unsigned long long m = __ballot(G != 0.f);
                 if (G != 0.f) {
                     const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_tiled_kernel(const Prot
                 if (p.g_rows) { const int k = pi - (int)p.row_label[b] * p.ppc; mine = mine && !(k >= 0 && k < p.ppc); }
                 if (mine) {
                     am = p.argmax[bp];
-                    G = gm * dact_dd(p.dist_full[bp * T + am], p.act_kind, p.eps);
+                    G = gm * dact_map(p, bp * T + am);
                     sg += G;
                 }
             }
@@ -782,7 +798,7 @@ __global__ __launch_bounds__(1024) void proto_bwd_protos_rows_kernel(const Proto
                 const bool in = t >= r0 && t < r0 + rows;
                 float g = in ? p.g_rows[((size_t)b * p.ppc + wave) * T + t] : 0.f;
                 if (in && t == am) g += gm;
-                Gt[h] = (g != 0.f) ? 2.0f * g * dact_dd(p.dist_full[bp * T + t], p.act_kind, p.eps) : 0.f;
+                Gt[h] = (g != 0.f) ? 2.0f * g * dact_map(p, bp * T + t) : 0.f;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1034,13 +1050,13 @@ static int proto_bwd_launch(ProtoBwdParams p, void* workspace, size_t workspace_
 }
 
 int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
-                  const float* dist_full, const float* g_full, const float* g_max, const int* argmax, float* dtok, int64_t dstride_b,
+                  const float* dist_full, int map_is_act, const float* g_full, const float* g_max, const int* argmax, float* dtok, int64_t dstride_b,
                   float* dprotos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && Dp > 0 && T >= 1 && Dp <= 512, PPF_ERR_SHAPE, "ppf_proto_bwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
     PPF_CHECK_ARG(tok && protos && dist_full && (g_full || g_max) && (T == 1 || argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd: null pointer");
     ProtoBwdParams p;
     p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
-    p.dist_full = dist_full; p.g_full = g_full; p.g_rows = nullptr; p.row_label = nullptr; p.ppc = 0; p.g_max = g_max;
+    p.dist_full = dist_full; p.map_is_act = map_is_act != 0; p.g_full = g_full; p.g_rows = nullptr; p.row_label = nullptr; p.ppc = 0; p.g_max = g_max;
     p.argmax = (T == 1) ? nullptr : argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
     return proto_bwd_launch(p, workspace, workspace_bytes, stream);
 }
@@ -1049,14 +1065,14 @@ int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float
 // prototypes of a sample's own class receive a gradient): g_rows [B][ppc][T] holds dL/d act_full[b][label[b]*ppc + k][t], every other
 // entry of the (B,P,T) gradient is zero and is never materialised, scanned or stored.  Same workspace contract as ppf_proto_bwd.
 int ppf_proto_bwd_rows(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
-                       const float* dist_full, const float* g_rows, const void* label_i64, int ppc, const float* g_max, const int* argmax,
+                       const float* dist_full, int map_is_act, const float* g_rows, const void* label_i64, int ppc, const float* g_max, const int* argmax,
                        float* dtok, int64_t dstride_b, float* dprotos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && P > 0 && P <= 8192 && Dp > 0 && T >= 2 && Dp <= 512 && ppc >= 1 && ppc <= P, PPF_ERR_SHAPE,
                   "ppf_proto_bwd_rows: bad shape B=%d P=%d Dp=%d T=%d ppc=%d", B, P, Dp, T, ppc);
     PPF_CHECK_ARG(tok && protos && dist_full && g_rows && label_i64 && (argmax || !g_max), PPF_ERR_ARG, "ppf_proto_bwd_rows: null pointer");
     ProtoBwdParams p;
     p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
-    p.dist_full = dist_full; p.g_full = nullptr; p.g_rows = g_rows; p.row_label = (const long long*)label_i64; p.ppc = ppc; p.g_max = g_max;
+    p.dist_full = dist_full; p.map_is_act = map_is_act != 0; p.g_full = nullptr; p.g_rows = g_rows; p.row_label = (const long long*)label_i64; p.ppc = ppc; p.g_max = g_max;
     p.argmax = argmax; p.dtok = dtok; p.dstride_b = dstride_b; p.dprotos = dprotos;
     return proto_bwd_launch(p, workspace, workspace_bytes, stream);
 }

@@ -371,11 +371,14 @@ def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_
     return act_max, argmax, dist, act
 
 
-def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4, rows=None):
+def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos, act_kind=0, eps=1e-4, rows=None, from_act=False):
     """Backward of proto_fwd.  g_full [B,P,T] is the dense gradient of the activation maps; rows = (g_rows [B,ppc,T], label int64 [B], ppc)
-    gives the same gradient in the block form of the PPC loss instead (ppf_proto_bwd_rows: nothing of shape (B,P,T) is touched)."""
+    gives the same gradient in the block form of the PPC loss instead (ppf_proto_bwd_rows: nothing of shape (B,P,T) is touched).
+    from_act: `dist` is the activation map act_full of the forward (the derivative is taken from it; T > 1 only)."""
     B, Ttot, Dp = tokens.shape
     P = protos.shape[0]
+    if T == 1 and from_act:
+        raise ValueError("proto_bwd: from_act applies to the pooled branch (T > 1)")
     if T == 1 and (g_full is None) != (g_max is None) and os.environ.get("PPF_PROTO_BWD_DENSE", "1") != "0":
         # one token per sample: every (sample, prototype) pair carries a gradient -> two dense fp32 products instead of the gather
         ws = _workspace(tokens.device, _lib.lib().ppf_proto_bwd_single_workspace(B, P, Dp))
@@ -392,10 +395,10 @@ def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos,
         if g_full is not None:
             raise ValueError("proto_bwd: pass the activation-map gradient either dense (g_full) or in block form (rows), not both")
         g_rows, label, ppc = rows
-        _lib.call("ppf_proto_bwd_rows", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_rows, label, int(ppc), g_max, argmax,
-                  dtok, Ttot * Dp, dprotos, ws, need)
+        _lib.call("ppf_proto_bwd_rows", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, int(from_act), g_rows, label, int(ppc), g_max,
+                  argmax, dtok, Ttot * Dp, dprotos, ws, need)
         return
-    _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, g_full, g_max, argmax, dtok,
+    _lib.call("ppf_proto_bwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), dist, int(from_act), g_full, g_max, argmax, dtok,
               Ttot * Dp, dprotos, ws, need)
 
 

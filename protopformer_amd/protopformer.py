@@ -54,6 +54,7 @@ def build_features(base_architecture, pretrained=False, img_size=224, drop_path=
 
 # ------------------------------------------------------------------------------------------------ autograd nodes
 _SIDE_FIRST = os.environ.get("PPF_PROTO_SIDE_FIRST", "1") != "0"
+_KEEP_DIST = os.environ.get("PPF_PROTO_KEEP_DIST", "0") != "0"      # A/B: write and save the (B,P,k) distance map in training as before round 5
 
 
 # The PPC loss only sends a gradient to the ppc prototypes of each sample's own class.  Instead of scattering it into a dense (B,P,T)
@@ -130,13 +131,16 @@ class ProtoLayerFn(torch.autograd.Function):
         pl = protos_local.reshape(protos_local.shape[0], Dp)
         pg = protos_global.reshape(protos_global.shape[0], Dp)
         need_bwd = any(ctx.needs_input_grad)
-        act_l, argmax, dist, act_full = ops.proto_fwd(f, 1, k, pl, act_kind, ppnet.epsilon, want_dist=need_bwd or want_dist, want_act=True)
+        # training keeps ONE (B,P,k) map: the backward takes d act / d dist from the activations themselves (ppf_proto_bwd map_is_act), so the
+        # distance map (166 MB at config 3) is only written when the caller asks for it (eval / push)
+        keep_dist = need_bwd and _KEEP_DIST
+        act_l, argmax, dist, act_full = ops.proto_fwd(f, 1, k, pl, act_kind, ppnet.epsilon, want_dist=keep_dist or want_dist, want_act=True)
         act_g, _, dist_g, _ = ops.proto_fwd(f, 0, 1, pg, act_kind, ppnet.epsilon, want_dist=need_bwd, want_act=False)
         ctx.set_materialize_grads(False)
         ppnet._last_argmax = argmax              # (B, P) int32: the token each local prototype's max-pool selected (tests, visualisation)
         if need_bwd:
-            ctx.save_for_backward(f, protos_local, protos_global)
-            ctx.aux = (argmax, dist, dist_g, act_kind, ppnet)
+            ctx.save_for_backward(f, protos_local, protos_global, dist if keep_dist else act_full)
+            ctx.aux = (argmax, not keep_dist, dist_g, act_kind, ppnet)
         if dist is None:
             dist = act_full.new_empty(0)
         ctx.mark_non_differentiable(dist)
@@ -144,8 +148,8 @@ class ProtoLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_l, g_full, g_g, _g_dist):
-        f, _, _ = ctx.saved_tensors
-        argmax, dist, dist_g, act_kind, ppnet = ctx.aux
+        f, _, _, dist = ctx.saved_tensors                 # dist: the distance map, or (from_act) the activation map
+        argmax, from_act, dist_g, act_kind, ppnet = ctx.aux
         protos_local, protos_global = ppnet.prototype_vectors, ppnet.prototype_vectors_global
         store = ppnet.flat_store()
         store.attach_all_grads()
@@ -163,11 +167,11 @@ class ProtoLayerFn(torch.autograd.Function):
             # the side stream starts on the prototype gradients BEFORE the main stream's token-gradient kernels are enqueued: the two
             # only share inputs, and the lane orders itself behind whatever the main stream has enqueued at submit time
             side_l = lambda: ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, None, store.grad_view(protos_local).reshape(-1, Dp),
-                                           act_kind, ppnet.epsilon, rows=rows)
+                                           act_kind, ppnet.epsilon, rows=rows, from_act=from_act)
             reads_l = [t for t in (f, dist, gf, gl, argmax) + (rows[:2] if rows is not None else ()) if t is not None]
             if _SIDE_FIRST:
                 lane.submit(side_l, reads_l, tag="PROTO")
-            ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, df, None, act_kind, ppnet.epsilon, rows=rows)
+            ops.proto_bwd(f, 1, T1 - 1, pl, dist, gf, gl, argmax, df, None, act_kind, ppnet.epsilon, rows=rows, from_act=from_act)
             if not _SIDE_FIRST:
                 lane.submit(side_l, reads_l, tag="PROTO")
         if g_g is not None:

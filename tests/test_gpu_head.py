@@ -174,6 +174,14 @@ def test_proto_fwd_bwd_vs_oracle(B, T, Dp, P):
     ops.proto_bwd(tokens.cuda(), t0, T, protos.cuda(), dist, gfull.cuda(), gmax.cuda(), argmax, dtok, dpro)
     assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens")
     assert_close(dpro, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes")
+    if T > 1:
+        # the training form: d act / d dist taken from the ACTIVATION map (the only (B,P,T) map a training forward writes)
+        dtok_a = torch.zeros_like(dtok); dpro_a = torch.zeros_like(dpro)
+        ops.proto_bwd(tokens.cuda(), t0, T, protos.cuda(), act, gfull.cuda(), gmax.cuda(), argmax, dtok_a, dpro_a, from_act=True)
+        assert_close(dtok_a, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens (from activations)")
+        assert_close(dpro_a, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes (from activations)")
+        assert_close(dtok_a, dtok, rtol=1e-4, atol=2e-5 * float(dtok.abs().max()), what="from activations vs from distances, tokens")
+        assert_close(dpro_a, dpro, rtol=1e-4, atol=2e-5 * float(dpro.abs().max()), what="from activations vs from distances, prototypes")
 
 
 @pytest.mark.parametrize("B,T,Dp,P,ppc", [(5, 9, 32, 20, 2), (3, 121, 192, 200, 10), (6, 81, 384, 300, 10), (300, 9, 64, 40, 4), (2, 121, 384, 48, 16),
@@ -210,6 +218,13 @@ def test_proto_bwd_block_rows_vs_oracle(B, T, Dp, P, ppc):
     ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, cu(gmax), argmax, dtok2, None, rows=blk)
     ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, cu(gmax), argmax, None, dpro2, rows=blk)
     assert torch.equal(dtok2, dtok) and torch.equal(dpro2, dpro), "separate calls differ from the combined one"
+    # the training form (derivative from the activation map) through the block-row kernels
+    dtok_a = torch.zeros_like(dtok); dpro_a = torch.zeros_like(dpro)
+    ops.proto_bwd(cu(tokens), 1, T, cu(protos), act, None, cu(gmax), argmax, dtok_a, dpro_a, rows=blk, from_act=True)
+    assert_close(dtok_a, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens (block rows, from activations)")
+    assert_close(dpro_a, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes (block rows, from activations)")
+    assert_close(dtok_a, dtok, rtol=1e-4, atol=2e-5 * float(dtok.abs().max()), what="from activations vs from distances, tokens")
+    assert_close(dpro_a, dpro, rtol=1e-4, atol=2e-5 * float(dpro.abs().max()), what="from activations vs from distances, prototypes")
     # the dense form of the same gradient agrees to rounding (different summation order)
     dtok3 = torch.zeros_like(dtok); dpro3 = torch.zeros_like(dpro)
     ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, cu(gfull), cu(gmax), argmax, dtok3, dpro3)
@@ -220,6 +235,32 @@ def test_proto_bwd_block_rows_vs_oracle(B, T, Dp, P, ppc):
     ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, None, None, None, None, dpro4, rows=blk)
     ops.proto_bwd(cu(tokens), 1, T, cu(protos), dist, cu(gfull), None, None, None, dpro5)
     assert_close(dpro4, dpro5, rtol=1e-3, atol=2e-5 * float(dpro5.abs().max()), what="rows only")
+
+
+def test_proto_bwd_from_activations_clipped_distance_known_answer():
+    """token == prototype: d = 0 exactly, the reference's relu clips there and autograd gives a ZERO gradient through that pair
+    (protopformer.py:216); the activation-map form must recognise the forward's own value at d = 0 and do the same -- and give the
+    closed-form derivative 1/(d+1) - 1/(d+eps) elsewhere."""
+    from protopformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, Dp, P = 2, 9, 32, 12
+    tokens = torch.randint(0, 16, (B, T + 1, Dp), generator=g).float() / 16          # exactly representable: d == 0 comes out exactly
+    protos = torch.randint(0, 16, (P, Dp), generator=g).float() / 16
+    protos[3] = tokens[0, 1 + 4]
+    protos[7] = tokens[1, 1 + 0]
+    act_max, argmax, dist, act = ops.proto_fwd(tokens.cuda(), 1, T, protos.cuda())
+    assert float(dist[0, 3, 4]) == 0.0 and float(dist[1, 7, 0]) == 0.0
+    assert int(argmax[0, 3]) == 4 and int(argmax[1, 7]) == 0
+    gmax = torch.zeros(B, P); gmax[0, 3] = 1.0; gmax[1, 7] = -2.0; gmax[0, 5] = 0.5
+    for from_act, m in ((False, dist), (True, act)):
+        dtok = torch.zeros(B, T + 1, Dp, device="cuda"); dpro = torch.zeros(P, Dp, device="cuda")
+        ops.proto_bwd(tokens.cuda(), 1, T, protos.cuda(), m, None, gmax.cuda(), argmax, dtok, dpro, from_act=from_act)
+        assert float(dpro[3].abs().max()) == 0.0 and float(dpro[7].abs().max()) == 0.0, from_act
+        t5 = int(argmax[0, 5]); d5 = float(dist[0, 5, t5])
+        coef = 0.5 * (1.0 / (d5 + 1.0) - 1.0 / (d5 + 1e-4))
+        want = coef * 2.0 * (protos[5] - tokens[0, 1 + t5])
+        assert_close(dpro[5], want, rtol=1e-4, atol=1e-5 * float(want.abs().max()), what=f"closed form (from_act={from_act})")
+        assert float(dtok[1].abs().max()) == 0.0, "sample 1 only touches the clipped pair"
 
 
 def test_ppc_loss_golden_and_grad():
