@@ -39,6 +39,7 @@ struct ProtoFwdParams {
     int* argmax;           // [B][P] (POOL only)
     float* dist_full;      // [B][P][T] or null
     float* act_full;       // [B][P][T] or null
+    uint32_t t_magic;      // ceil(2^32 / T) (T >= 2): f / T == umulhi(f, t_magic) for the f < 2^11 the map stores divide
 };
 
 __device__ __forceinline__ float activation(float d, int kind, float eps) {
@@ -99,7 +100,9 @@ __device__ __forceinline__ void proto_fwd_epilogue(const ProtoFwdParams& p, f32x
         if (!dst) continue;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
-            __syncthreads();
+            // the transpose tile is private to the wave (the callers' barrier separates it from the operand stage it overlays): ordering
+            // inside one wave needs no workgroup barrier -- LDS executes a wave's instructions in issue order
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (((lane & 31) >> 4) == half) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
@@ -109,7 +112,7 @@ __device__ __forceinline__ void proto_fwd_epilogue(const ProtoFwdParams& p, f32x
                         xp[(lane & 15) * (ROWS + 1) + row] = pass == 0 ? acc[t][r] : activation(acc[t][r], p.act_kind, p.eps);
                     }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const int pf = pw + 16 * half;               // first prototype of this half
             const int np = min(16, p.P - pf);            // prototypes of this half that exist
             if (np <= 0) continue;
@@ -120,14 +123,14 @@ __device__ __forceinline__ void proto_fwd_epilogue(const ProtoFwdParams& p, f32x
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int ff = min(f + e, total - 1), pp = ff / p.T, tt = ff - pp * p.T;
+                        const int ff = min(f + e, total - 1), pp = (int)__umulhi((uint32_t)ff, p.t_magic), tt = ff - pp * p.T;   // ff / T
                         v[e] = xp[pp * (ROWS + 1) + tt];
                     }
                     if (f + 4 <= total) *reinterpret_cast<float4*>(obase + f) = make_float4(v[0], v[1], v[2], v[3]);
                     else for (int e = 0; f + e < total; ++e) obase[f + e] = v[e];
                 }
             } else {
-                for (int f = lane; f < total; f += 64) { const int pp = f / p.T, tt = f - pp * p.T; obase[f] = xp[pp * (ROWS + 1) + tt]; }
+                for (int f = lane; f < total; f += 64) { const int pp = (int)__umulhi((uint32_t)f, p.t_magic), tt = f - pp * p.T; obase[f] = xp[pp * (ROWS + 1) + tt]; }
             }
         }
     }
@@ -955,6 +958,7 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
     ProtoFwdParams p;
     p.tok = tok; p.stride_b = stride_b; p.t0 = t0; p.T = T; p.protos = protos; p.B = B; p.P = P; p.Dp = Dp; p.act_kind = act_kind; p.eps = eps;
     p.act_max = act_max; p.argmax = argmax; p.dist_full = dist_full; p.act_full = act_full;
+    p.t_magic = T >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)T - 1) / (uint64_t)T) : 0u;
     const int gx = (P + PB - 1) / PB;
     // algorithmic work: the (B T) x Dp . Dp x P contraction; tokens + prototypes in, the maps that are asked for + max / arg-max out
     PpfProbeScope probe(PPF_PROBE_PROTO_FWD, stream, 2.0 * B * T * (double)Dp * P,
