@@ -89,7 +89,7 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
 
 /* ---- fp32 verification mode, backward (csrc/precise.hip, round 5; DeiT): never on the measured path -----------------------------
  * LayerNorm backward with the statistics recomputed from x (rows of dy <-> rows row_map[r] of x, dx_out written at the x rows, dw / db by
- * fp32 atomics); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale, 3 product, 4 row scale x LayerScale column); column sums; Attention backward with the
+ * fp32 atomics); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale, 3 product, 4 row scale x LayerScale column, 5 ReLU' from its output); column sums; Attention backward with the
  * policy softmax of deit:29-43 (scratch: B*H*2*N*N floats). */
 int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
                           int rows, int D, float eps, ppf_stream_t stream);
@@ -361,7 +361,8 @@ int ppf_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int
 int ppf_im2col_patch_f32(const float* img, float* cols, int B, int C, int H, int W, int patch, ppf_stream_t stream);
 int ppf_layernorm_fwd_f32(const float* x, const int* row_map, const float* w, const float* b, float* y, int rows, int D, float eps,
                           ppf_stream_t stream);
-/* in place on C[M][N]: kind 0 +bias | 1 gelu_erf(+bias) | 2 sigmoid(+bias) | 3 res + rowscale[m/rows_per_group]*colscale[n]*(C+bias) */
+/* in place on C[M][N]: kind 0 +bias | 1 gelu_erf(+bias) | 2 sigmoid(+bias) | 3 res + rowscale[m/rows_per_group]*colscale[n]*(C+bias) |
+ * 4 relu(+bias) (the bottleneck add-on head, protopformer.py:90-107) */
 int ppf_epilogue_f32(float* C, const float* bias, int kind, const float* res, const float* rowscale, int rows_per_group,
                      const float* colscale, int M, int N, ppf_stream_t stream);
 /* deit:29-60 on fp32 qkv [B*N][3D]; headmean (optional) [B][N][NP] = mean over heads of the probabilities (deit:104) */

@@ -285,9 +285,17 @@ def cait_features(sd: SD, img: Tensor, heads: int, depth: int, reserve_layer: in
 # Prototype layer (protopformer.py)
 # --------------------------------------------------------------------------------------
 def addon_sigmoid(sd: SD, tokens: Tensor) -> Tensor:
-    """add_on_layers 'regular': Conv2d 1x1 + Sigmoid (protopformer.py:111-114, 171-172) on (B,T,D) tokens."""
-    w = sd["add_on_layers.0.weight"]
-    return torch.sigmoid(linear(tokens, w.reshape(w.shape[0], -1), sd["add_on_layers.0.bias"]))
+    """add_on_layers on (B,T,D) tokens (protopformer.py:171-172).  'regular' (protopformer.py:111-114): Conv2d 1x1 + Sigmoid.
+    'bottleneck' (protopformer.py:90-107, the signature default): pairs of 1x1 convolutions, the width halved pair by pair down to the
+    prototype dimension, ReLU after every convolution except the last, which is followed by the Sigmoid.  The structure is read off the
+    state dict: Sequential indices 0, 2, 4, ... hold the convolutions (the activations between them carry no parameters)."""
+    idxs = sorted({int(k.split(".")[1]) for k in sd if k.startswith("add_on_layers.") and k.endswith(".weight")})
+    x = tokens
+    for n, i in enumerate(idxs):
+        w = sd[f"add_on_layers.{i}.weight"]
+        x = linear(x, w.reshape(w.shape[0], -1), sd[f"add_on_layers.{i}.bias"])
+        x = torch.sigmoid(x) if n == len(idxs) - 1 else torch.relu(x)
+    return x
 
 
 def l2_distances(tokens: Tensor, protos: Tensor) -> Tensor:

@@ -9,6 +9,7 @@ import functools
 import os
 
 import torch
+import torch.nn as nn
 
 from . import _lib, ops
 from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, EPI_SIGMOID_F32
@@ -202,10 +203,48 @@ def head_tokens_fwd(ppnet, store, x, idx):
     k = idx.shape[1]
     row_map = gather_rows_map(idx, N) if N != 1 + k else None
     nf, meanf, rstdf = ops.layernorm_fwd(x.reshape(B * N, D), feats.norm.weight, feats.norm.bias, LN_EPS, row_map=row_map)
-    conv = ppnet.add_on_layers[0]
-    Dp = conv.out_channels
-    f = ops.gemm(nf, store.w16(conv.weight).reshape(Dp, D), epi=EPI_SIGMOID_F32, bias=conv.bias)
-    return f.reshape(B, 1 + k, Dp), dict(row_map=row_map, nf=nf, meanf=meanf, rstdf=rstdf)
+    f, chain = addon_fwd(ppnet, store, nf)
+    return f.reshape(B, 1 + k, f.shape[-1]), dict(row_map=row_map, nf=nf, meanf=meanf, rstdf=rstdf, chain=chain)
+
+
+def addon_convs(ppnet):
+    """The 1x1 convolutions of add_on_layers in order: one ('regular', protopformer.py:111-114) or the bottleneck chain
+    (protopformer.py:90-107) -- ReLU between them, Sigmoid after the last."""
+    return [m for m in ppnet.add_on_layers if isinstance(m, nn.Conv2d)]
+
+
+def addon_fwd(ppnet, store, nf):
+    """nf bf16 [rows, D] (final-norm output of the reserved rows) -> (f fp32 [rows, Dp], what addon_bwd needs).
+    'regular': one MFMA GEMM with the sigmoid in its epilogue.  'bottleneck': the first convolution on the same GEMM (fp32 out), the narrow
+    tail (widths D/2 ... Dp on 1 + k rows per sample: < 1 % of the step's flops) in fp32 through ppf_sgemm."""
+    convs = addon_convs(ppnet)
+    c0 = convs[0]
+    w0 = store.w16(c0.weight).reshape(c0.out_channels, -1)
+    if len(convs) == 1:
+        return ops.gemm(nf, w0, epi=EPI_SIGMOID_F32, bias=c0.bias), None
+    h = ops.relu_f32_(ops.gemm(nf, w0, epi=EPI_F32, bias=c0.bias))
+    acts = []
+    for j, c in enumerate(convs[1:]):
+        acts.append(h)
+        h = ops.linear_f32(h, c.weight, c.bias, kind=2 if j == len(convs) - 2 else 4)
+    return h, acts
+
+
+def addon_bwd(ppnet, store, head, f, df):
+    """-> dz bf16 [rows, C0]: gradient w.r.t. the FIRST convolution's pre-activation (its bias gradient and every parameter gradient of the
+    tail are accumulated here); the callers do the first convolution's weight / input gradients on the bf16 GEMMs as before."""
+    convs = addon_convs(ppnet)
+    gv = store.grad_view
+    if len(convs) == 1:
+        return ops.sigmoid_bwd(df, f, gv(convs[0].bias))
+    acts = head["chain"]
+    d = ops.ew_bwd_f32(1, df.contiguous(), f)                                    # sigmoid'
+    for j in reversed(range(1, len(convs))):
+        c, x_in = convs[j], acts[j - 1]
+        ops.linear_wgrad_f32(d, x_in, gv(c.weight), gv(c.bias))
+        d = ops.ew_bwd_f32(5, ops.linear_dgrad_f32(d, c.weight), x_in)          # through the ReLU that produced x_in
+    ops.colsum_f32(d, gv(convs[0].bias))
+    return ops.cast_bf16(d)
 
 
 # ------------------------------------------------------------------------------------------------ DeiT backward
@@ -351,14 +390,13 @@ def deit_backward(ppnet, store, saved, df):
     B, N, D = x_last.shape
     M = B * N
     dev = x_last.device
-    conv = ppnet.add_on_layers[0]
-    Dp = conv.out_channels
-    # add-on: sigmoid' then the two GEMMs
+    conv = addon_convs(ppnet)[0]
+    # add-on: sigmoid' (and the fp32 tail of a bottleneck head) then the two GEMMs of its first convolution
     lane = wgrad_lane(store)
     lnb = functools.partial(ops.layernorm_bwd, lane=lane, defer_reduce=True)      # column-sum reductions (parameter grads): side stream
-    dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), store.grad_view(conv.bias))
+    dz = addon_bwd(ppnet, store, head, saved["f"].reshape(-1, saved["f"].shape[-1]), df)
     _wgrad(store, dz, head["nf"], conv.weight)
-    dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
+    dnf = ops.gemm(dz, store.w16(conv.weight).reshape(conv.out_channels, D), trans_b=True, epi=EPI_BF16)
     # final norm backward scatters into the (zero) residual-stream gradient; also emits the bf16 gradient of the last fc2
     # (x_last is already the reserved rows when the last blocks ran compacted: then nothing is scattered here)
     alloc = ops.zeros if head["row_map"] is not None else (lambda shape, dtype, device: torch.empty(shape, dtype=dtype, device=device))

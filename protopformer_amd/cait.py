@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .backbone import LN_EPS, _dp, _wgrad, head_tokens_fwd, wgrad_lane
+from .backbone import LN_EPS, _dp, _wgrad, addon_bwd, addon_convs, head_tokens_fwd, wgrad_lane
 from .deit import _Mlp, _PatchEmbed, _init_vit
 from .ops import EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID
 
@@ -302,14 +302,13 @@ def cait_backward(ppnet, store, saved, df):
     N, H = N1 - 1, feats.num_heads
     M = B * N
     dev = u_last.device
-    conv = ppnet.add_on_layers[0]
-    Dp = conv.out_channels
+    conv = addon_convs(ppnet)[0]
     gv = store.grad_view
     lane = wgrad_lane(store)
     lnb = functools.partial(ops.layernorm_bwd, lane=lane)      # column-sum reductions (parameter grads) go to the side stream
-    dz = ops.sigmoid_bwd(df, saved["f"].reshape(-1, Dp), gv(conv.bias))
+    dz = addon_bwd(ppnet, store, head, saved["f"].reshape(-1, saved["f"].shape[-1]), df)
     _wgrad(store, dz, head["nf"], conv.weight)
-    dnf = ops.gemm(dz, store.w16(conv.weight).reshape(Dp, D), trans_b=True, epi=EPI_BF16)
+    dnf = ops.gemm(dz, store.w16(conv.weight).reshape(conv.out_channels, D), trans_b=True, epi=EPI_BF16)
     du = ops.zeros((B * N1, D), torch.float32, dev)
     lnb(dnf, u_last.reshape(B * N1, D), feats.norm.weight, head["meanf"], head["rstdf"], gv(feats.norm.weight),
                       gv(feats.norm.bias), dx_out=du, row_map=head["row_map"])

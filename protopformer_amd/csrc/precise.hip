@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void epilogue_f32_kernel(float* __restrict__ C
         if (kind == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         else if (kind == 2) v = 1.0f / (1.0f + expf(-v));
         else if (kind == 3) v = res[i] + (rowscale ? rowscale[m / rows_per_group] : 1.0f) * (colscale ? colscale[n] : 1.0f) * v;
+        else if (kind == 4) v = fmaxf(v, 0.f);
         C[i] = v;
     }
 }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
 
 // elementwise backward pieces on [M][N]: kind 0: out = a * gelu'(b) (exact erf form, b = pre-activation) | 1: out = a * b * (1 - b) (sigmoid, b = its
 // output) | 2: out = a * rowscale[m / rows_per_group] (DropPath factor on a branch gradient; rowscale == NULL: copy) | 3: out = a * b |
-// 4: out = a * rowscale[m / rows_per_group] * b[n] (b = a LayerScale vector [N])
+// 4: out = a * rowscale[m / rows_per_group] * b[n] (b = a LayerScale vector [N]) | 5: out = b > 0 ? a : 0 (ReLU, b = its output)
 __global__ __launch_bounds__(256) void ew_bwd_f32_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                          const float* __restrict__ rowscale, int rows_per_group, int M, int N) {
     const int64_t total = (int64_t)M * N;
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void ew_bwd_f32_kernel(int kind, const float* 
         } else if (kind == 1) v *= b[i] * (1.0f - b[i]);
         else if (kind == 2) v *= rowscale ? rowscale[(int)(i / N) / rows_per_group] : 1.0f;
         else if (kind == 3) v *= b[i];
+        else if (kind == 5) v = b[i] > 0.f ? v : 0.f;
         else v *= (rowscale ? rowscale[(int)(i / N) / rows_per_group] : 1.0f) * b[i % N];
         out[i] = v;
     }
@@ -387,7 +389,7 @@ int ppf_layernorm_fwd_f32(const float* x, const int* row_map, const float* w, co
 
 int ppf_epilogue_f32(float* C, const float* bias, int kind, const float* res, const float* rowscale, int rows_per_group, const float* colscale,
                      int M, int N, hipStream_t stream) {
-    PPF_CHECK_ARG(M > 0 && N > 0 && kind >= 0 && kind <= 3 && (kind != 3 || res), PPF_ERR_ARG, "ppf_epilogue_f32: bad arguments");
+    PPF_CHECK_ARG(M > 0 && N > 0 && kind >= 0 && kind <= 4 && (kind != 3 || res), PPF_ERR_ARG, "ppf_epilogue_f32: bad arguments");
     hipLaunchKernelGGL(epilogue_f32_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, stream, C, bias, kind, res, rowscale,
                        rows_per_group > 0 ? rows_per_group : 1, colscale, M, N);
     PPF_LAUNCH_CHECK();
@@ -593,9 +595,9 @@ int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, c
 }
 
 // kind 0: out = a * gelu'(b) | 1: out = a * b * (1 - b) | 2: out = a * rowscale[m / rows_per_group] (rowscale NULL: copy) | 3: out = a * b |
-// 4: out = a * rowscale[..] * b[n] (LayerScale column vector); out may alias a
+// 4: out = a * rowscale[..] * b[n] (LayerScale column vector) | 5: out = b > 0 ? a : 0; out may alias a
 int ppf_ew_bwd_f32(int kind, const float* a, const float* b, float* out, const float* rowscale, int rows_per_group, int M, int N, hipStream_t stream) {
-    PPF_CHECK_ARG(a && out && M > 0 && N > 0 && kind >= 0 && kind <= 4 && (kind == 2 || b), PPF_ERR_ARG, "ppf_ew_bwd_f32: bad arguments");
+    PPF_CHECK_ARG(a && out && M > 0 && N > 0 && kind >= 0 && kind <= 5 && (kind == 2 || b), PPF_ERR_ARG, "ppf_ew_bwd_f32: bad arguments");
     hipLaunchKernelGGL(ew_bwd_f32_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, stream, kind, a, b, out, rowscale, rows_per_group > 0 ? rows_per_group : 1, M, N);
     PPF_LAUNCH_CHECK();
     return 0;

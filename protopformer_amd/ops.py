@@ -752,7 +752,7 @@ def layernorm_bwd_f32(dy, x, w, dw, db, dx_out, dres_in=None, row_map=None, eps=
 
 def ew_bwd_f32(kind, a, b=None, rowscale=None, rows_per_group=1):
     """kind 0: a * gelu'(b) | 1: a * b * (1 - b) | 2: a * rowscale[row // rows_per_group] (rowscale None: copy) | 3: a * b |
-    4: a * rowscale[..] * b[col] (b a LayerScale vector)."""
+    4: a * rowscale[..] * b[col] (b a LayerScale vector) | 5: a where b > 0 else 0 (ReLU', b = the ReLU's output)."""
     M, N = a.shape
     out = torch.empty_like(a)
     _lib.call("ppf_ew_bwd_f32", int(kind), a, b, out, rowscale, rows_per_group, M, N)
@@ -801,4 +801,11 @@ def class_attn_bwd_f32(q, k, v, policy, dout, B, H, N1, D):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     _lib.call("ppf_class_attn_bwd_f32", q, k, v, policy, dout, dq, dk, dv, B, H, N1, D)
     return dq, dk, dv
+
+
+def relu_f32_(x):
+    """in place max(x, 0) on an fp32 [M, N] matrix."""
+    M, N = x.shape
+    _lib.call("ppf_epilogue_f32", x, None, 4, None, None, 1, None, M, N)
+    return x
 

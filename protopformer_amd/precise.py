@@ -12,7 +12,7 @@ Reference lines: deit:172-240, cait:303-345, protopformer.py:141-173."""
 import torch
 
 from . import ops
-from .backbone import LN_EPS, _dp
+from .backbone import LN_EPS, _dp, addon_convs
 
 
 def _mlp(blk, x1, N, s2, colscale=None):
@@ -46,11 +46,21 @@ def deit_tokens(ppnet, img, dp, saved=None):
         x = _mlp(blk, x1, N, _dp(dp, 2 * i + 1))
     rows = ops.reserved_rows_map(idx, N)
     nf = ops.layernorm_fwd_f32(x, feats.norm.weight, feats.norm.bias, LN_EPS, row_map=rows)          # deit:238 on the reserved rows
-    conv = ppnet.add_on_layers[0]
-    f = ops.linear_f32(nf, conv.weight, conv.bias, kind=2)                                          # protopformer.py:162-172
+    f, acts = _addon_fwd(ppnet, nf)                                                                 # protopformer.py:162-172
     if saved is not None:
-        saved.update(cols=cols, layers=layers, x_last=x, rows=rows, nf=nf, f=f, shape=(B, N, D), dp=dp)
-    return f.reshape(B, 1 + k, conv.out_channels), cls_attn, idx
+        saved.update(cols=cols, layers=layers, x_last=x, rows=rows, nf=nf, f=f, acts=acts, shape=(B, N, D), dp=dp)
+    return f.reshape(B, 1 + k, f.shape[-1]), cls_attn, idx
+
+
+def _addon_fwd(ppnet, nf):
+    """add_on_layers on the normalised reserved rows: Linear (+ ReLU ...) + Sigmoid; returns (f, inputs of the convolutions after the first)."""
+    convs = addon_convs(ppnet)
+    h, acts = nf, []
+    for j, c in enumerate(convs):
+        if j:
+            acts.append(h)
+        h = ops.linear_f32(h, c.weight, c.bias, kind=2 if j == len(convs) - 1 else 4)
+    return h, acts
 
 
 def _gv(store, p):
@@ -68,8 +78,12 @@ def _linear_bwd(store, dy, x, lin, want_dx=True):
 def _head_bwd(ppnet, store, saved, df, rows_total, D):
     """add-on conv + sigmoid + final norm on the reserved rows: gradient w.r.t. the last token matrix (rows outside the reservation zero)."""
     feats = ppnet.features
-    dz = ops.ew_bwd_f32(1, df, saved["f"])                                                          # sigmoid'
-    dnf = _linear_bwd(store, dz, saved["nf"], ppnet.add_on_layers[0])
+    convs = addon_convs(ppnet)
+    d = ops.ew_bwd_f32(1, df, saved["f"])                                                           # sigmoid'
+    for j in reversed(range(1, len(convs))):                                                        # bottleneck tail (protopformer.py:90-107)
+        x_in = saved["acts"][j - 1]
+        d = ops.ew_bwd_f32(5, _linear_bwd(store, d, x_in, convs[j]), x_in)                          # ... through the ReLU that produced x_in
+    dnf = _linear_bwd(store, d, saved["nf"], convs[0])
     dx = ops.zeros((rows_total, D), torch.float32, df.device)
     ops.layernorm_bwd_f32(dnf, saved["x_last"], feats.norm.weight, _gv(store, feats.norm.weight), _gv(store, feats.norm.bias), dx,
                           row_map=saved["rows"], eps=LN_EPS)
@@ -182,11 +196,10 @@ def cait_tokens(ppnet, img, dp, saved=None):
     u_out = torch.cat([cls.reshape(B, 1, D), xt], dim=1).reshape(B * N1, D)
     rows = ops.reserved_rows_map(idx, N1)
     nf = ops.layernorm_fwd_f32(u_out, feats.norm.weight, feats.norm.bias, LN_EPS, row_map=rows)     # cait:343 on the reserved rows
-    conv = ppnet.add_on_layers[0]
-    f = ops.linear_f32(nf, conv.weight, conv.bias, kind=2)
+    f, acts = _addon_fwd(ppnet, nf)
     if saved is not None:
-        saved.update(cols=cols, layers=layers, tlayers=tlayers, x_last=u_out, rows=rows, nf=nf, f=f, shape=(B, N, D), dp=dp)
-    return f.reshape(B, 1 + k, conv.out_channels), cls_attn, idx
+        saved.update(cols=cols, layers=layers, tlayers=tlayers, x_last=u_out, rows=rows, nf=nf, f=f, acts=acts, shape=(B, N, D), dp=dp)
+    return f.reshape(B, 1 + k, f.shape[-1]), cls_attn, idx
 
 
 def _layerscale_bwd(store, d, y, gamma, rowscale, N):

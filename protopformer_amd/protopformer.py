@@ -293,8 +293,6 @@ class PPNet(nn.Module):
         if not use_global or len(reserve_layers) != 1:
             # the reference's use_global=False / empty reserve_layers branches are broken (SURVEY quick facts)
             raise NotImplementedError("only the working reference configuration is supported: use_global=True with one reserve layer")
-        if add_on_layers_type == 'bottleneck':
-            raise NotImplementedError("add_on_layers_type='bottleneck' is outside the hot path (main.py:49 passes 'regular')")
         if prototype_activation_function not in ('log', 'linear'):
             raise NotImplementedError("prototype_activation_function must be 'log' or 'linear'")
         self.img_size = img_size
@@ -326,7 +324,18 @@ class PPNet(nn.Module):
         assert int(round(math.sqrt(k))) ** 2 == k, "reserve token number must be a perfect square (protopformer.py:165)"
         in_ch = features.embed_dim
         self.num_patches = features.patch_embed.num_patches
-        self.add_on_layers = nn.Sequential(nn.Conv2d(in_ch, self.prototype_shape[1], kernel_size=1), nn.Sigmoid())
+        if add_on_layers_type == 'bottleneck':
+            # protopformer.py:90-107 (the signature default): pairs of 1x1 convolutions, the width halved pair by pair down to the prototype
+            # dimension; ReLU after each, Sigmoid after the last.  Same Sequential indices (0, 2, 4, ...) as the reference's state dict.
+            mods, cur, dp = [], in_ch, self.prototype_shape[1]
+            while cur > dp or not mods:
+                out = max(dp, cur // 2)
+                mods += [nn.Conv2d(cur, out, kernel_size=1), nn.ReLU(), nn.Conv2d(out, out, kernel_size=1)]
+                mods.append(nn.ReLU() if out > dp else nn.Sigmoid())
+                cur = cur // 2
+            self.add_on_layers = nn.Sequential(*mods)
+        else:
+            self.add_on_layers = nn.Sequential(nn.Conv2d(in_ch, self.prototype_shape[1], kernel_size=1), nn.Sigmoid())
         self.prototype_vectors = nn.Parameter(torch.rand(self.prototype_shape), requires_grad=True)
         self.prototype_vectors_global = nn.Parameter(torch.rand(self.prototype_shape_global), requires_grad=True)
         self.ones = nn.Parameter(torch.ones(self.prototype_shape), requires_grad=False)

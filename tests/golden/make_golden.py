@@ -65,7 +65,7 @@ def split_groups(model):
     ]
 
 
-def micro_fixture(kind, path, seed):
+def micro_fixture(kind, path, seed, add_on='regular', proto_dim=32):
     torch.manual_seed(seed)
     if kind == 'deit':
         feats = ref_deit.MyVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=6, num_heads=2, mlp_ratio=4,
@@ -78,11 +78,11 @@ def micro_fixture(kind, path, seed):
                                 num_classes=10, drop_rate=0., drop_path_rate=0.)
         del feats.head
         reserve_layer, meta = 1, dict(arch='cait', dim=96, depth=5, heads=2)
-    model = ref.PPNet(features=feats, img_size=64, prototype_shape=[20, 32, 1, 1], proto_layer_rf_info=None,
+    model = ref.PPNet(features=feats, img_size=64, prototype_shape=[20, proto_dim, 1, 1], proto_layer_rf_info=None,
                       num_classes=10, reserve_layers=[reserve_layer], reserve_token_nums=[9], use_global=True,
                       use_ppc_loss=True, ppc_cov_thresh=1., ppc_mean_thresh=2., global_coe=0.5,
                       global_proto_per_class=2, init_weights=True, prototype_activation_function='log',
-                      add_on_layers_type='regular')
+                      add_on_layers_type=add_on)
     randomize(model, seed + 1)
     g = torch.Generator().manual_seed(seed + 2)
     img = torch.randn(4, 3, 64, 64, generator=g)
@@ -92,8 +92,10 @@ def micro_fixture(kind, path, seed):
     out.update(img=np32(img), label=label.numpy())
     for k, v in meta.items():
         out[f'meta/{k}'] = np.array(v)
+    if add_on != 'regular':
+        out['meta/add_on'] = np.array(add_on)
     out.update({'meta/reserve_layer': np.array(reserve_layer), 'meta/reserve_k': np.array(9), 'meta/img': np.array(64),
-                'meta/num_prototypes': np.array(20), 'meta/proto_dim': np.array(32), 'meta/num_classes': np.array(10),
+                'meta/num_prototypes': np.array(20), 'meta/proto_dim': np.array(proto_dim), 'meta/num_classes': np.array(10),
                 'meta/global_per_class': np.array(2), 'meta/global_coe': np.array(0.5)})
 
     model.eval()
@@ -210,4 +212,6 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     micro_fixture('deit', os.path.join(HERE, 'micro_deit.npz'), seed=101)
     micro_fixture('cait', os.path.join(HERE, 'micro_cait.npz'), seed=202)
+    # the reference's DEFAULT add-on head (protopformer.py:90-107): 64 -> 32 ReLU 32 -> 32 ReLU, 32 -> 16 ReLU 16 -> 16 Sigmoid
+    micro_fixture('deit', os.path.join(HERE, 'micro_deit_bottleneck.npz'), seed=303, add_on='bottleneck', proto_dim=16)
     ops_fixture(os.path.join(HERE, 'ops_real.npz'))

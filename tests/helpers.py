@@ -19,7 +19,7 @@ def micro(name):
     cfg = dict(arch=m["arch"], dim=m["dim"], depth=m["depth"], heads=m["heads"], reserve_layer=m["reserve_layer"],
                reserve_k=m["reserve_k"], global_coe=m["global_coe"], num_prototypes=m["num_prototypes"],
                proto_dim=m["proto_dim"], num_classes=m["num_classes"], global_per_class=m["global_per_class"],
-               protos_per_class=m["num_prototypes"] // m["num_classes"], img=m["img"], patch=16)
+               protos_per_class=m["num_prototypes"] // m["num_classes"], img=m["img"], patch=16, add_on=m.get("add_on", "regular"))
     return sd, cfg, z
 
 
@@ -90,7 +90,7 @@ def build_micro(cfg, sd):
     m = PPNet(features=feats, img_size=cfg["img"], prototype_shape=[cfg["num_prototypes"], cfg["proto_dim"], 1, 1], proto_layer_rf_info=None,
               num_classes=cfg["num_classes"], reserve_layers=[cfg["reserve_layer"]], reserve_token_nums=[cfg["reserve_k"]], use_global=True,
               use_ppc_loss=True, ppc_cov_thresh=1., ppc_mean_thresh=2., global_coe=cfg["global_coe"],
-              global_proto_per_class=cfg["global_per_class"], add_on_layers_type="regular")
+              global_proto_per_class=cfg["global_per_class"], add_on_layers_type=cfg.get("add_on", "regular"))
     m.load_state_dict(sd, strict=True)
     return m.cuda()
 

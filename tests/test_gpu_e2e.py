@@ -89,6 +89,103 @@ def test_micro_deit_eval_train_against_reference_fixture():
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
 
+def test_bottleneck_chain_matches_fp32_chain():
+    """backbone.addon_fwd / addon_bwd (first convolution on the bf16 MFMA GEMM, fp32 tail) against the all-fp32 chain of the verification mode
+    on a bf16-representable input: outputs and saved activations to bf16 rounding; the backward evaluated with the SAME ReLU gates
+    (the product's activations) to the rounding of its bf16 result -- parameter gradients of the tail included."""
+    from helpers import build_micro
+    from protopformer_amd import backbone, ops, precise
+    sd, cfg, z = micro("micro_deit_bottleneck.npz")
+    m = build_micro(cfg, sd).train()
+    store = m.flat_store()
+    store.refresh_bf16()
+    g = torch.Generator().manual_seed(0)
+    nf16 = torch.randn(40, 64, generator=g).cuda().bfloat16()
+    f_p, acts_p = backbone.addon_fwd(m, store, nf16)
+    f_r, acts_r = precise._addon_fwd(m, nf16.float())
+    assert rel_err(f_p, f_r) < 2e-3 and all(rel_err(a, b) < 4e-3 for a, b in zip(acts_p, acts_r)), (rel_err(f_p, f_r), [rel_err(a, b) for a, b in zip(acts_p, acts_r)])
+    assert len(acts_p) == 3 and [tuple(a.shape) for a in acts_p] == [(40, 32), (40, 32), (40, 16)]
+    df = torch.randn(40, 16, generator=g).cuda()
+    convs = backbone.addon_convs(m)
+    store.attach_all_grads()
+    for c in convs:
+        ops.zero_(store.grad_view(c.weight)); ops.zero_(store.grad_view(c.bias))
+    dz = backbone.addon_bwd(m, store, dict(chain=acts_p), f_p, df)
+    got = {i: (store.grad_view(c.weight).clone(), store.grad_view(c.bias).clone()) for i, c in enumerate(convs)}
+    # the fp32 chain backward on the same activations (torch, fp32)
+    d = df * f_p * (1 - f_p)
+    for j in (3, 2, 1):
+        w = convs[j].weight.detach().reshape(convs[j].out_channels, -1)
+        assert_close(got[j][0].reshape(w.shape), d.t() @ acts_p[j - 1], rtol=1e-4, atol=1e-5 * float((d.t() @ acts_p[j - 1]).abs().max()), what=f"tail weight gradient {j}")
+        assert_close(got[j][1], d.sum(0), rtol=1e-4, atol=1e-5 * float(d.sum(0).abs().max()), what=f"tail bias gradient {j}")
+        d = (d @ w) * (acts_p[j - 1] > 0)
+    assert_close(got[0][1], d.sum(0), rtol=1e-4, atol=1e-5 * float(d.sum(0).abs().max()), what="first bias gradient")
+    assert_close(dz.float(), d, rtol=4e-3, atol=4e-3 * float(d.abs().max()), what="gradient w.r.t. the first pre-activation (bf16)")
+
+
+def test_micro_deit_bottleneck_head_product_path_against_reference_fixture():
+    """The reference's DEFAULT add-on head (add_on_layers_type='bottleneck', protopformer.py:90-107: 64 -> 32 -> 32 -> 16 -> 16 here) on the
+    bf16 product path against the reference-generated fixture: reservation, logits, losses, every gradient's direction, and one optimizer
+    step through the flat AdamW (the tail's eight tensors live in the add-on group, lr 3e-3)."""
+    from protopformer_amd.engine import FlatAdamW
+    from protopformer_amd.protopformer import CrossEntropyLoss
+    from helpers import build_micro
+    sd, cfg, z = micro("micro_deit_bottleneck.npz")
+    assert cfg["add_on"] == "bottleneck"
+    m = build_micro(cfg, sd)
+    assert [k for k in m.state_dict() if k.startswith("add_on_layers.")] == [k for k in sd if k.startswith("add_on_layers.")]
+    img, label = torch.from_numpy(z["img"]).cuda(), torch.from_numpy(z["label"]).cuda()
+    m.eval()
+    logits, (cls_attn, dist, lg, ll) = m(img)
+    ref_idx = torch.from_numpy(z["eval/cls_token_attn"]).topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0]
+    assert torch.equal(cls_attn.cpu().topk(cfg["reserve_k"], dim=-1)[1].sort(dim=-1)[0], ref_idx)
+    report("micro_bottleneck_eval", logits=rel_err(logits, z["eval/logits"]), dist=rel_err(dist, z["eval/distances"]))
+    assert rel_err(logits, z["eval/logits"]) < 3e-3, rel_err(logits, z["eval/logits"])
+    assert_elementwise(logits, z["eval/logits"], 3e-3, "eval logits (bottleneck head)")
+    assert rel_err(dist, z["eval/distances"]) < 3e-3
+    m.train()
+    opt = FlatAdamW(m, weight_decay=0.05)
+    logits, aux = m(img)
+    ce = CrossEntropyLoss()(logits, label)
+    cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label)
+    loss = ce + 0.1 * cov + 0.5 * mean
+    report("micro_bottleneck_train", loss=rel_err(loss, z["train/loss"]), ce=rel_err(ce, z["train/ce"]))
+    assert rel_err(loss, z["train/loss"]) < 1e-3, (float(loss), float(z["train/loss"]))
+    opt.zero_grad()
+    loss.backward()
+    cos = {}
+    for name, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        g = p.grad.detach().float().cpu().reshape(-1)
+        if f"grad/{name}" in z.files:
+            ref = torch.from_numpy(z[f"grad/{name}"]).reshape(-1)
+        else:
+            g = g[torch.from_numpy(z[f"grad_idx/{name}"])]; ref = torch.from_numpy(z[f"grad_val/{name}"])
+        if float(ref.abs().max()) < 1e-7:
+            continue
+        cos[name] = float(torch.dot(g, ref) / (g.norm() * ref.norm()))
+    assert all(f"add_on_layers.{i}.{t}" in cos for i in (0, 2, 4, 6) for t in ("weight", "bias"))
+    # Everything downstream of the first ReLU layers agrees as on the 'regular' fixture.  Upstream of them the bf16 backbone perturbs the
+    # pre-activations by ~1e-3, so a few of the 40 x 32 ReLU units (measured: 1-4) sit on the other side of zero than in the fp32
+    # reference and gate a whole unit's gradient differently: per-tensor cosines 0.93-0.98 on this 40-row fixture (a property of bf16
+    # activations in front of a ReLU, not of the kernels -- test_bottleneck_chain_matches_fp32_chain holds the chain itself, and the fp32
+    # mode holds every gradient of this fixture to 1e-3, test_gpu_precise.py).
+    report("micro_bottleneck_grads", worst_cos=min(cos.values()), worst_downstream=min(v for k, v in cos.items() if k.startswith(("prototype", "add_on_layers.4", "add_on_layers.6"))))
+    for k, v in cos.items():
+        floor = 0.9998 if k.startswith(("prototype", "add_on_layers.4", "add_on_layers.6")) else 0.85      # measured worst 0.905 (deterministic)
+        assert v >= floor, f"gradient direction mismatch vs reference: {k} {v}"
+    opt.step()
+    torch.cuda.synchronize()
+    # AdamW's first step is lr * sign(g) where |g| >> eps: compare where the reference gradient is well above rounding noise
+    for i in (4, 6):
+        name = f"add_on_layers.{i}.weight"
+        p = dict(m.named_parameters())[name].detach().float().cpu()
+        big = torch.from_numpy(z[f"grad/{name}"]).abs() > 1e-4
+        assert_close(p[big], torch.from_numpy(z[f"step/{name}"])[big], rtol=1e-3, atol=2e-4, what=f"step/{name}")
+
+
 # gradient-cosine floor of test_real_shape_train_step_vs_oracle (same reservation, same max-pool routing; measured value in its comments)
 COS_FLOOR = 0.98          # measured 0.9921
 

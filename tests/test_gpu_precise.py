@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 rel fp32"
 
 
-@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz"])
+@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz", "micro_deit_bottleneck.npz"])
 def test_precise_forward_and_loss_match_reference_fixture(name):
     from protopformer_amd.protopformer import CrossEntropyLoss
     sd, cfg, z = micro(name)
@@ -51,7 +51,7 @@ def test_precise_forward_and_loss_match_reference_fixture(name):
             assert rel_err(val, z[f"train/{nm}"]) < TOL, (nm, float(val), float(z[f"train/{nm}"]))
 
 
-@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz"])
+@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz", "micro_deit_bottleneck.npz"])
 def test_precise_backward_matches_reference_gradients(name):
     """fp32 forward + fp32 backward of the DeiT / CaiT micro models against grad/* of the reference-generated fixture (autograd of the
     reference itself): EVERY parameter gradient within 1e-3 of its tensor's scale, element by element.  The bf16 step of the product

@@ -11,7 +11,7 @@ torch.set_num_threads(4)
 TOL = dict(rtol=1e-4, atol=1e-5)     # oracle vs reference, fp32 CPU both (observed ~1e-6)
 
 
-@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz"])
+@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz", "micro_deit_bottleneck.npz"])
 def test_micro_eval_and_train_forward(name):
     sd, cfg, z = micro(name)
     img, label = torch.from_numpy(z["img"]), torch.from_numpy(z["label"])
@@ -32,7 +32,7 @@ def test_micro_eval_and_train_forward(name):
     assert torch.equal(out["reserve_idx"], ref_idx)
 
 
-@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz"])
+@pytest.mark.parametrize("name", ["micro_deit.npz", "micro_cait.npz", "micro_deit_bottleneck.npz"])
 def test_micro_loss_grads_and_adamw_step(name):
     sd, cfg, z = micro(name)
     img, label = torch.from_numpy(z["img"]), torch.from_numpy(z["label"])
