@@ -359,6 +359,9 @@ def main():
     if os.environ.get("PPF_BENCH_ONE_GPU", "0") != "0":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if os.environ.get("PPF_MAIN_PRIORITY"):
+        # A/B: run the main chain on a HIP stream of the given priority (-1 = high; the weight-gradient lane stays at the default)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["PPF_MAIN_PRIORITY"])))
     if args.wgrad_alone:
         print(json.dumps(wgrad_uncontended(cfg, batch, torch.device("cuda", local_rank))), flush=True)
         return
