@@ -248,7 +248,11 @@ int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, ppf_stre
  * sample b's token i is at tok + b*stride_b + (t0+i)*Dp (fp32); T tokens per sample (T == 1: global / cls branch).
  * act_kind 0: log((d+1)/(d+eps)), 1: -d.  Outputs act_max [B][P], argmax [B][P], optional dist_full/act_full [B][P][T]. */
 int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
-                  float eps, float* act_max, int* argmax, float* dist_full, float* act_full, ppf_stream_t stream);
+                  float eps, float* act_max, int* argmax, float* dist_full, float* act_full, void* workspace, size_t workspace_bytes,
+                  ppf_stream_t stream);
+/* workspace: optional scratch of ppf_proto_fwd_workspace(P, Dp) bytes (any content, 16-byte aligned) -- the prototypes split ONCE per launch
+ * into the bf16 piece planes the pooled kernel reads (NULL: every workgroup splits its own rows; same results to fp32 summation order). */
+size_t ppf_proto_fwd_workspace(int P, int Dp);
 int ppf_proto_bwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind,
                   float eps, const float* dist_full, int map_is_act, const float* g_full, const float* g_max, const int* argmax, float* dtok,
                   int64_t dstride_b, float* dprotos, void* zeroed_workspace, size_t workspace_bytes, ppf_stream_t stream);

@@ -45,7 +45,7 @@ SIGS = {
     "ppf_rollout_threshold": "p" "iiii" "p" "s",
     "ppf_rollout_compact_layer": "p" "iiii" "f" "p" "s",
     "ppf_rollout_compact": "p" "iii" "p" "iiii" "f" "i" "ppp" "s",
-    "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "s",
+    "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "pz" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "pi" "pppp" "l" "p" "pz" "s",
     "ppf_proto_bwd_rows": "pliip" "iiii" "f" "pi" "pp" "i" "ppp" "l" "p" "pz" "s",
     "ppf_proto_bwd_single": "plip" "iiii" "f" "ppp" "l" "p" "pz" "s",
@@ -123,6 +123,8 @@ def lib():
         _lib.ppf_rollout_compact_bytes.restype = ctypes.c_size_t
         _lib.ppf_rollout_compact_bytes.argtypes = [ctypes.c_int] * 2
         _lib.ppf_proto_bwd_workspace.restype = ctypes.c_size_t
+        _lib.ppf_proto_fwd_workspace.restype = ctypes.c_size_t
+        _lib.ppf_proto_fwd_workspace.argtypes = [ctypes.c_int] * 2
         _lib.ppf_proto_bwd_workspace.argtypes = [ctypes.c_int] * 6
         _lib.ppf_layernorm_bwd_blocks.restype = ctypes.c_int
         _lib.ppf_layernorm_bwd_blocks.argtypes = [ctypes.c_int]

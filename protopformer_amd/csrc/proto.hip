@@ -39,6 +39,9 @@ struct ProtoFwdParams {
     int* argmax;           // [B][P] (POOL only)
     float* dist_full;      // [B][P][T] or null
     float* act_full;       // [B][P][T] or null
+    const uint4* pre;      // proto_fwd6_kernel<.., PRE = true>: the prototypes split once per launch into three bf16 piece planes in FRAGMENT
+                           // order [32-prototype block][16-step][piece][lane] x 16 bytes (proto_presplit_kernel), |p|^2 in pre_p2 [P rounded up to 32]
+    const float* pre_p2;
     uint32_t t_magic;      // ceil(2^32 / T) (T >= 2): f / T == umulhi(f, t_magic) for the f < 2^11 the map stores divide
 };
 
@@ -154,7 +157,32 @@ __device__ __forceinline__ Split3 split3(float lo, float hi) {
 }
 __device__ __forceinline__ int p6_off(int r, int c16) { return r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4); }   // 128-byte rows, chunk swizzle
 
-template <int TT, bool POOL>
+// Prototype operand of proto_fwd6_kernel<.., PRE>: one wave per 16-step of a 32-prototype block splits that lane's 8 contraction values
+// (prototype = block * 32 + (lane & 31), k = step * 16 + 8 (lane >> 5) ..) into the three bf16 pieces and stores them where the main kernel's
+// wave reads them with ONE coalesced 1 KiB load per piece (instead of 64 strided 32-byte reads + 44 VALU per 16-step and wave, repeated by
+// every one of the B workgroups that share the block); |p|^2 as the plain fp32 sum.  grid = ceil(P / 32) blocks of 256 threads.
+__global__ __launch_bounds__(256) void proto_presplit_kernel(const float* __restrict__ protos, int P, int Dp, uint4* __restrict__ pre, float* __restrict__ p2) {
+    __shared__ float part[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, l31 = lane & 31, KS = Dp / 16;
+    const int row = min((int)blockIdx.x * 32 + l31, P - 1);
+    const float* prow = protos + (size_t)row * Dp + 8 * hh;
+    float acc = 0.f;
+    for (int s = wave; s < KS; s += 4) {
+        const float4 u0 = *reinterpret_cast<const float4*>(prow + s * 16), u1 = *reinterpret_cast<const float4*>(prow + s * 16 + 4);
+        acc += u0.x * u0.x + u0.y * u0.y + u0.z * u0.z + u0.w * u0.w + u1.x * u1.x + u1.y * u1.y + u1.z * u1.z + u1.w * u1.w;
+        const Split3 b0 = split3(u0.x, u0.y), b1 = split3(u0.z, u0.w), b2 = split3(u1.x, u1.y), b3 = split3(u1.z, u1.w);
+        uint4* dst = pre + ((size_t)blockIdx.x * KS + s) * 192 + lane;
+        dst[0] = make_uint4(b0.a, b1.a, b2.a, b3.a);
+        dst[64] = make_uint4(b0.b, b1.b, b2.b, b3.b);
+        dst[128] = make_uint4(b0.c, b1.c, b2.c, b3.c);
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (hh == 0) part[wave][l31] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) p2[blockIdx.x * 32 + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+template <int TT, bool POOL, bool PRE>
 __global__ __launch_bounds__(256, TT <= 3 ? 3 : 2) void proto_fwd6_kernel(const ProtoFwdParams p) {
     constexpr int ROWS = TT * 32, BK6 = 64;
     constexpr int PLANE = ROWS * 128;                              // bytes: [ROWS][64 bf16], one piece
@@ -216,8 +244,17 @@ __global__ __launch_bounds__(256, TT <= 3 ? 3 : 2) void proto_fwd6_kernel(const 
         u1 = *reinterpret_cast<const float4*>(prow + kk + 4);
     };
     float4 q0, q1;
+    // PRE: the pieces come pre-split in fragment order (proto_presplit_kernel): three coalesced 16-byte loads per lane and 16-step
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const int KS = p.Dp / 16;
+    const uint4* pre = PRE ? p.pre + ((size_t)(blockIdx.x * (PB / 32) + wave) * KS) * 192 + lane : nullptr;
+    uint4 ra, rb, rc;
+    auto pload3 = [&](int step) __attribute__((always_inline)) {
+        const uint4* b = pre + (size_t)min(step, KS - 1) * 192;
+        ra = b[0]; rb = b[64]; rc = b[128];
+    };
     gload(0);
-    pload(0, q0, q1);
+    if constexpr (PRE) pload3(0); else pload(0, q0, q1);
     for (int k0 = 0; k0 < p.Dp; k0 += BK6) {
         __syncthreads();                                             // everyone finished reading the previous chunk
         sstore();
@@ -226,14 +263,22 @@ __global__ __launch_bounds__(256, TT <= 3 ? 3 : 2) void proto_fwd6_kernel(const 
 #pragma unroll
         for (int ks = 0; ks < BK6 / 16; ++ks) {
             if (k0 + ks * 16 < p.Dp) {
-                const float4 u0 = q0, u1 = q1;
-                pload(k0 + ks * 16 + 16, q0, q1);                    // next 16-step (clamped re-read at the end)
-                p2p += u0.x * u0.x + u0.y * u0.y + u0.z * u0.z + u0.w * u0.w + u1.x * u1.x + u1.y * u1.y + u1.z * u1.z + u1.w * u1.w;
-                const Split3 b0 = split3(u0.x, u0.y), b1 = split3(u0.z, u0.w), b2 = split3(u1.x, u1.y), b3 = split3(u1.z, u1.w);
-                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-                const bf16x8 pa = __builtin_bit_cast(bf16x8, (u32x4){b0.a, b1.a, b2.a, b3.a});
-                const bf16x8 pb = __builtin_bit_cast(bf16x8, (u32x4){b0.b, b1.b, b2.b, b3.b});
-                const bf16x8 pc = __builtin_bit_cast(bf16x8, (u32x4){b0.c, b1.c, b2.c, b3.c});
+                bf16x8 pa, pb, pc;
+                if constexpr (PRE) {
+                    const uint4 ua = ra, ub = rb, uc = rc;
+                    pload3(k0 / 16 + ks + 1);                          // next 16-step (clamped re-read at the end)
+                    pa = __builtin_bit_cast(bf16x8, (u32x4){ua.x, ua.y, ua.z, ua.w});
+                    pb = __builtin_bit_cast(bf16x8, (u32x4){ub.x, ub.y, ub.z, ub.w});
+                    pc = __builtin_bit_cast(bf16x8, (u32x4){uc.x, uc.y, uc.z, uc.w});
+                } else {
+                    const float4 u0 = q0, u1 = q1;
+                    pload(k0 + ks * 16 + 16, q0, q1);                // next 16-step (clamped re-read at the end)
+                    p2p += u0.x * u0.x + u0.y * u0.y + u0.z * u0.z + u0.w * u0.w + u1.x * u1.x + u1.y * u1.y + u1.z * u1.z + u1.w * u1.w;
+                    const Split3 b0 = split3(u0.x, u0.y), b1 = split3(u0.z, u0.w), b2 = split3(u1.x, u1.y), b3 = split3(u1.z, u1.w);
+                    pa = __builtin_bit_cast(bf16x8, (u32x4){b0.a, b1.a, b2.a, b3.a});
+                    pb = __builtin_bit_cast(bf16x8, (u32x4){b0.b, b1.b, b2.b, b3.b});
+                    pc = __builtin_bit_cast(bf16x8, (u32x4){b0.c, b1.c, b2.c, b3.c});
+                }
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     const int off = p6_off(t * 32 + l31, ks * 2 + hh);
@@ -251,7 +296,7 @@ __global__ __launch_bounds__(256, TT <= 3 ? 3 : 2) void proto_fwd6_kernel(const 
             }
         }
     }
-    const float p2 = p2p + __shfl_xor(p2p, 32, 64);
+    const float p2 = PRE ? p.pre_p2[p0 + wave * 32 + l31] : p2p + __shfl_xor(p2p, 32, 64);
     __syncthreads();
     // |x|^2 per row: the 16 threads that staged a row's float4 pieces are 16 consecutive lanes
 #pragma unroll
@@ -951,8 +996,15 @@ extern "C" {
 // tokens: fp32 rows of Dp values; sample b's token i is at tok + b*stride_b + (t0+i)*Dp, T tokens per sample
 // (T == 1: the global/cls branch, no pooling).  protos [P][Dp].  act_kind 0 = 'log', 1 = 'linear'.
 // Outputs: act_max [B][P], argmax [B][P] (T > 1), optional dist_full / act_full [B][P][T].
+// workspace (optional, ppf_proto_fwd_workspace(P, Dp) bytes, any content): the pre-split prototype planes of the pooled branch; NULL or too
+// small: every workgroup splits its prototype rows itself (same results: the pieces are the same numbers, |p|^2 is summed in another order).
+size_t ppf_proto_fwd_workspace(int P, int Dp) {
+    const size_t rows = (size_t)((P + PB - 1) / PB) * PB;
+    return rows * (size_t)Dp * 6 + rows * sizeof(float);
+}
+
 int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float* protos, int B, int P, int Dp, int act_kind, float eps,
-                  float* act_max, int* argmax, float* dist_full, float* act_full, hipStream_t stream) {
+                  float* act_max, int* argmax, float* dist_full, float* act_full, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     PPF_CHECK_ARG(B > 0 && P > 0 && Dp > 0 && Dp % 4 == 0 && T >= 1 && T <= 128, PPF_ERR_SHAPE, "ppf_proto_fwd: bad shape B=%d P=%d Dp=%d T=%d", B, P, Dp, T);
     PPF_CHECK_ARG(tok && protos && act_max && (T == 1 || argmax), PPF_ERR_ARG, "ppf_proto_fwd: null pointer");
     ProtoFwdParams p;
@@ -965,18 +1017,34 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
                         4.0 * ((double)B * T * Dp + (double)P * Dp + (double)B * P * T * ((dist_full ? 1 : 0) + (act_full ? 1 : 0)) + 2.0 * B * P));
     // default: the split-bf16 contraction; PPF_PROTO_FP32=1 (or Dp not a multiple of 16): the fp32-MFMA kernel
     static const int fp32_mfma = getenv("PPF_PROTO_FP32") ? atoi(getenv("PPF_PROTO_FP32")) : 0;
+    static const int presplit = getenv("PPF_PROTO_PRESPLIT") ? atoi(getenv("PPF_PROTO_PRESPLIT")) : 1;
     const bool x6 = !fp32_mfma && Dp % 16 == 0;
+    const bool pre = x6 && presplit && T > 1 && workspace && workspace_bytes >= ppf_proto_fwd_workspace(P, Dp) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    if (pre) {
+        p.pre = reinterpret_cast<const uint4*>(workspace);
+        float* p2 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)gx * PB * Dp * 6);
+        p.pre_p2 = p2;
+        hipLaunchKernelGGL(proto_presplit_kernel, dim3(gx * (PB / 32)), dim3(256), 0, stream, protos, P, Dp, reinterpret_cast<uint4*>(workspace), p2);
+    } else { p.pre = nullptr; p.pre_p2 = nullptr; }
     if (T == 1) {
-        if (x6) hipLaunchKernelGGL((proto_fwd6_kernel<2, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
+        if (x6) hipLaunchKernelGGL((proto_fwd6_kernel<2, false, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((proto_fwd_kernel<2, false>), dim3(gx, (B + 63) / 64), dim3(256), 0, stream, p);
     } else {
         const int tt = (T + 31) / 32;
         if (x6) {
             switch (tt) {
-                case 1: hipLaunchKernelGGL((proto_fwd6_kernel<1, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
-                case 2: hipLaunchKernelGGL((proto_fwd6_kernel<2, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
-                case 3: hipLaunchKernelGGL((proto_fwd6_kernel<3, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
-                default: hipLaunchKernelGGL((proto_fwd6_kernel<4, true>), dim3(gx, B), dim3(256), 0, stream, p); break;
+                case 1: if (pre) hipLaunchKernelGGL((proto_fwd6_kernel<1, true, true>), dim3(gx, B), dim3(256), 0, stream, p);
+                        else hipLaunchKernelGGL((proto_fwd6_kernel<1, true, false>), dim3(gx, B), dim3(256), 0, stream, p);
+                        break;
+                case 2: if (pre) hipLaunchKernelGGL((proto_fwd6_kernel<2, true, true>), dim3(gx, B), dim3(256), 0, stream, p);
+                        else hipLaunchKernelGGL((proto_fwd6_kernel<2, true, false>), dim3(gx, B), dim3(256), 0, stream, p);
+                        break;
+                case 3: if (pre) hipLaunchKernelGGL((proto_fwd6_kernel<3, true, true>), dim3(gx, B), dim3(256), 0, stream, p);
+                        else hipLaunchKernelGGL((proto_fwd6_kernel<3, true, false>), dim3(gx, B), dim3(256), 0, stream, p);
+                        break;
+                default: if (pre) hipLaunchKernelGGL((proto_fwd6_kernel<4, true, true>), dim3(gx, B), dim3(256), 0, stream, p);
+                        else hipLaunchKernelGGL((proto_fwd6_kernel<4, true, false>), dim3(gx, B), dim3(256), 0, stream, p);
+                        break;
             }
         } else {
             switch (tt) {

@@ -367,7 +367,9 @@ def proto_fwd(tokens, t0, T, protos, act_kind=0, eps=1e-4, want_dist=True, want_
     argmax = torch.empty((B, P), dtype=torch.int32, device=dev) if T > 1 else None
     dist = torch.empty((B, P, T), dtype=torch.float32, device=dev) if want_dist else None
     act = torch.empty((B, P, T), dtype=torch.float32, device=dev) if want_act else None
-    _lib.call("ppf_proto_fwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), act_max, argmax, dist, act)
+    ws = _workspace(dev, _lib.lib().ppf_proto_fwd_workspace(P, Dp)) if T > 1 else None      # pre-split prototype planes (per-stream scratch)
+    _lib.call("ppf_proto_fwd", tokens, Ttot * Dp, t0, T, protos, B, P, Dp, act_kind, float(eps), act_max, argmax, dist, act,
+              ws, ws.numel() if ws is not None else 0)
     return act_max, argmax, dist, act
 
 
