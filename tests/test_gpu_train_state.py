@@ -310,7 +310,7 @@ def test_graphed_step_equals_eager_step():
     assert l2a == l2b
 
 
-@pytest.mark.parametrize("arch", ["deit", "cait"])
+@pytest.mark.parametrize("arch", ["deit", "cait", "deit-bottleneck"])
 def test_replayed_step_equals_eager_step(arch):
     """engine.ReplayedTrainStep (recorded command list) against the eager step: same losses and bit-identical parameters, moments and EMA
     after warm-up + recording + 3 replays with changing batches, clipping on, DropPath on (device-side counter), lr changed between steps
@@ -318,6 +318,8 @@ def test_replayed_step_equals_eager_step(arch):
     from protopformer_amd import backbone
     from protopformer_amd.engine import FlatAdamW, ReplayedTrainStep, train_one_step
     from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
+    addon = "bottleneck" if arch.endswith("bottleneck") else "regular"      # (the reference's default head: 192 -> 96 -> 96 -> 64 -> 64 here)
+    arch = arch.split("-")[0]
     name = "deit_tiny_patch16_224" if arch == "deit" else "cait_xxs24_224"
     layer, k = (11, 81) if arch == "deit" else (1, 121)
 
@@ -325,7 +327,7 @@ def test_replayed_step_equals_eager_step(arch):
         backbone._KEEP_CACHE.clear()
         torch.manual_seed(3)
         m = construct_PPNet(name, pretrained=False, img_size=224, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[layer],
-                            reserve_token_nums=[k], use_global=True, use_ppc_loss=True, global_proto_per_class=5, add_on_layers_type="regular").cuda().train()
+                            reserve_token_nums=[k], use_global=True, use_ppc_loss=True, global_proto_per_class=5, add_on_layers_type=addon).cuda().train()
         if arch == "cait":                        # DropPath replay is covered bit for bit by the DeiT variant; CaiT's check below needs equal draws
             for blk in list(m.features.blocks) + list(m.features.blocks_token_only):
                 blk.drop_path_rate = 0.0
