@@ -237,6 +237,29 @@ def test_proto_bwd_block_rows_vs_oracle(B, T, Dp, P, ppc):
     assert_close(dpro4, dpro5, rtol=1e-3, atol=2e-5 * float(dpro5.abs().max()), what="rows only")
 
 
+@pytest.mark.parametrize("from_act", [False, True])
+def test_proto_linear_activation_pooled_backward(from_act):
+    """prototype_activation_function='linear' (act = -d, protopformer.py:222-225) through the pooled branch: forward maps and the backward
+    from the distance map and from the activation map (d act / d dist = -1 where d > 0) against autograd of the oracle."""
+    from protopformer_amd import ops
+    B, T, Dp, P = 3, 9, 32, 20
+    g = torch.Generator().manual_seed(21)
+    tokens = torch.rand(B, T + 1, Dp, generator=g)
+    protos = torch.rand(P, Dp, generator=g)
+    xt = tokens.clone().requires_grad_(True); pr = protos.clone().requires_grad_(True)
+    mx, d_ref, a_ref = O.proto_activations(xt[:, 1:1 + T], pr, activation="linear")
+    gmax = torch.randn(B, P, generator=g)
+    gfull = torch.zeros(B, P, T); gfull[:, :3] = torch.randn(B, 3, T, generator=g)
+    ((mx * gmax).sum() + (a_ref * gfull).sum()).backward()
+    act_max, argmax, dist, act = ops.proto_fwd(tokens.cuda(), 1, T, protos.cuda(), act_kind=1)
+    assert_close(act, a_ref.detach(), rtol=1e-3, atol=1e-5 * Dp, what="linear activation map")
+    assert_close(act_max, mx.detach(), rtol=1e-3, atol=1e-5 * Dp, what="linear max-pooled activation")
+    dtok = torch.zeros(B, T + 1, Dp, device="cuda"); dpro = torch.zeros(P, Dp, device="cuda")
+    ops.proto_bwd(tokens.cuda(), 1, T, protos.cuda(), act if from_act else dist, gfull.cuda(), gmax.cuda(), argmax, dtok, dpro, act_kind=1, from_act=from_act)
+    assert_close(dtok, xt.grad, rtol=2e-3, atol=2e-3 * float(xt.grad.abs().max()), what="d tokens (linear)")
+    assert_close(dpro, pr.grad, rtol=2e-3, atol=2e-3 * float(pr.grad.abs().max()), what="d prototypes (linear)")
+
+
 def test_proto_bwd_from_activations_clipped_distance_known_answer():
     """token == prototype: d = 0 exactly, the reference's relu clips there and autograd gives a ZERO gradient through that pair
     (protopformer.py:216); the activation-map form must recognise the forward's own value at d = 0 and do the same -- and give the
