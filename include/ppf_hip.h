@@ -76,7 +76,8 @@ int ppf_gemm_probe_read(double* ms_total, int64_t* launches, double* flops, doub
 /* Path probe (round 5): the same mechanism around the kernels BASELINE.json's north_star names -- tag 0 attention forward
  * (ppf_attn_fwd / ppf_attn_fwd_hm), 1 attention backward (ppf_attn_bwd), 2 prototype forward (ppf_proto_fwd) -- for bench.py's
  * roofline.named_path.  ppf_path_probe(1) clears and starts, (0) stops, (2) stops and destroys the pools; ppf_path_probe_read
- * returns the summed in-step kernel time, the launch count and the algorithmic flops / bytes of the recorded launches. */
+ * returns the summed in-step kernel time, the launch count and the algorithmic flops / bytes of the recorded launches.
+ * Single-threaded and eager-only: launches into a capturing stream are not recorded, and at most 4096 launches per tag are kept. */
 int ppf_path_probe(int enable);
 int ppf_path_probe_read(int tag, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
@@ -88,8 +89,8 @@ int ppf_gemm_bf16_batched(const void* A, const void* B, void* C, int M, int N, i
                           int64_t sb_o, int64_t sb_i, int64_t sc_o, int64_t sc_i, int kpad, ppf_stream_t stream);
 
 /* ---- fp32 verification mode, backward (csrc/precise.hip, round 5; DeiT): never on the measured path -----------------------------
- * LayerNorm backward with the statistics recomputed from x (rows of dy <-> rows row_map[r] of x, dx_out written at the x rows, dw / db by
- * fp32 atomics); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale, 3 product, 4 row scale x LayerScale column, 5 ReLU' from its output); column sums; Attention backward with the
+ * LayerNorm backward with the statistics recomputed from x (rows of dy <-> rows row_map[r] of x, dx_out written at the x rows -- dx_out may
+ * alias dres_in; dw / db by fp32 atomics, either may be NULL for a frozen LayerNorm); elementwise pieces (kind 0 x gelu'(pre), 1 sigmoid', 2 DropPath row scale, 3 product, 4 row scale x LayerScale column, 5 ReLU' from its output); column sums; Attention backward with the
  * policy softmax of deit:29-43 (scratch: B*H*2*N*N floats). */
 int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
                           int rows, int D, float eps, ppf_stream_t stream);

@@ -244,8 +244,15 @@ __device__ __forceinline__ bf16x8 frag_tr16(const unsigned char* tile, int kb, i
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int HD, int NT16, bool POLICY>
+// TAIL (round 6, no policy only): N > 16 (NT16 - 1), i.e. only the LAST key tile holds padded keys -- the softmax then runs on the packed fp32
+// pipe with no per-element select: exponent and row sum as v_pk_fma_f32 / v_pk_add_f32, the P.V operand is bf16(e) itself, and the policy
+// softmax's +eps/N enters the head-mean map as ONE per-row constant (eps/N) sum_h 1/(sum_h + eps) added at the store.  The same term of
+// the OUTPUT, (eps/N)/(sum + eps) sum_j v_j, is dropped there: without a policy sum >= 1 (the row maximum contributes e = 1), so it is
+// <= N (eps/N) max|v| = 1e-6 max|v| -- 4 000 x below the bf16 rounding of `out`.  With a policy a row's kept mass can be arbitrarily small
+// (its maximum may sit on a masked key), so that instantiation keeps the exact per-element form.
+template <int HD, int NT16, bool POLICY, bool TAIL>
 __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParams p) {
+    static_assert(!(POLICY && TAIL), "the packed softmax is the no-policy path");
     static_assert(HD == 64, "128-byte rows");
     constexpr int KS = HD / 32, DB = HD / 16, ROWS = NT16 * 16, BUF = Fwd16<HD, NT16>::BUF;
     constexpr int NPIECE = 2 * ROWS / 8, PPW = (NPIECE + F16_WAVES - 1) / F16_WAVES;      // 1 KiB pieces (8 rows) of K then V; pieces per wave
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
     f32x4 mean[NT16];
 #pragma unroll
     for (int t = 0; t < NT16; ++t) mean[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float czsum = 0.f;                                 // TAIL: (eps / N) sum_h 1 / (sum_h + eps), the eps term of this query row's head mean
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
         const unsigned char* tK = lds16 + (h & 1) * BUF;
@@ -326,22 +334,42 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
         mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
         const float m1 = mraw * c1;
         float sum = 0.f;
+        if constexpr (TAIL) {
+            const ppf_float2 c12 = {c1, c1}, nm = {-m1, -m1};
+            ppf_float2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            const int key0 = t * 16 + 4 * grp;
-            float keep[4] = {1.f, 1.f, 1.f, 1.f};
-            if constexpr (POLICY) {
-                const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
-                keep[0] = kp.x; keep[1] = kp.y; keep[2] = kp.z; keep[3] = kp.w;
+            for (int t = 0; t < NT16; ++t) {
+                const ppf_float2 x0 = ppf_float2{s[t][0], s[t][1]} * c12 + nm, x1 = ppf_float2{s[t][2], s[t][3]} * c12 + nm;
+                ppf_float2 e0, e1;
+                e0.x = __builtin_amdgcn_exp2f(x0.x); e0.y = __builtin_amdgcn_exp2f(x0.y);
+                e1.x = __builtin_amdgcn_exp2f(x1.x); e1.y = __builtin_amdgcn_exp2f(x1.y);
+                if (t == NT16 - 1) {                                   // the only tile with padded keys (their K rows repeat row N - 1)
+                    const int key0 = t * 16 + 4 * grp;
+                    e0.x = key0 < N ? e0.x : 0.f; e0.y = key0 + 1 < N ? e0.y : 0.f;
+                    e1.x = key0 + 2 < N ? e1.x : 0.f; e1.y = key0 + 3 < N ? e1.y : 0.f;
+                }
+                sum2 += e0; sum2 += e1;
+                s[t] = f32x4{e0.x, e0.y, e1.x, e1.y};                  // unnormalised probability WITHOUT the eps / N term (see above)
             }
+            sum = sum2.x + sum2.y;
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool real = key0 + i < N;
-                float e = __builtin_amdgcn_exp2f(s[t][i] * c1 - m1);
-                if constexpr (POLICY) e *= (key0 + i == qself) ? 1.0f : keep[i];
-                else e = real ? e : 0.f;
-                sum += e;
-                s[t][i] = e + (real ? c : 0.f);                    // unnormalised probability (+ eps / N on the real keys)
+            for (int t = 0; t < NT16; ++t) {
+                const int key0 = t * 16 + 4 * grp;
+                float keep[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (POLICY) {
+                    const float4 kp = *reinterpret_cast<const float4*>(pol + key0);
+                    keep[0] = kp.x; keep[1] = kp.y; keep[2] = kp.z; keep[3] = kp.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool real = key0 + i < N;
+                    float e = __builtin_amdgcn_exp2f(s[t][i] * c1 - m1);
+                    if constexpr (POLICY) e *= (key0 + i == qself) ? 1.0f : keep[i];
+                    else e = real ? e : 0.f;
+                    sum += e;
+                    s[t][i] = e + (real ? c : 0.f);                    // unnormalised probability (+ eps / N on the real keys)
+                }
             }
         }
         sum += __shfl_xor(sum, 16, 64);
@@ -353,10 +381,21 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
             p.zinv[si] = zi;
         }
         if (p.headmean) {
+            if constexpr (TAIL) {
+                const ppf_float2 z2 = {zi, zi};
+                czsum += c * zi;
 #pragma unroll
-            for (int t = 0; t < NT16; ++t)
+                for (int t = 0; t < NT16; ++t) {
+                    const ppf_float2 lo = ppf_float2{s[t][0], s[t][1]} * z2 + ppf_float2{mean[t][0], mean[t][1]};
+                    const ppf_float2 hi = ppf_float2{s[t][2], s[t][3]} * z2 + ppf_float2{mean[t][2], mean[t][3]};
+                    mean[t] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mean[t][i] += s[t][i] * zi;
+                for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mean[t][i] += s[t][i] * zi;
+            }
         }
         f32x4 o[DB];
 #pragma unroll
@@ -386,7 +425,13 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
 #pragma unroll
         for (int t = 0; t < NT16; ++t) {
             const int key0 = t * 16 + 4 * grp;
-            if (key0 < p.NP) *reinterpret_cast<float4*>(row + key0) = make_float4(mean[t][0] * invH, mean[t][1] * invH, mean[t][2] * invH, mean[t][3] * invH);
+            float4 v = make_float4(mean[t][0] * invH, mean[t][1] * invH, mean[t][2] * invH, mean[t][3] * invH);
+            if constexpr (TAIL) {
+                const float cz = czsum * invH;
+                if (t < NT16 - 1) { v.x += cz; v.y += cz; v.z += cz; v.w += cz; }
+                else { v.x += key0 < N ? cz : 0.f; v.y += key0 + 1 < N ? cz : 0.f; v.z += key0 + 2 < N ? cz : 0.f; v.w += key0 + 3 < N ? cz : 0.f; }
+            }
+            if (key0 < p.NP) *reinterpret_cast<float4*>(row + key0) = v;
         }
     }
 }
@@ -1009,17 +1054,21 @@ int ppf_attn_fwd_hm(const void* qkv, void* out, const float* policy, float* rowm
     constexpr int lds6 = Fwd16<64, 6>::LDS, lds13 = Fwd16<64, 13>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<64, 13, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds13);
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(attn_fwd16): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
+    static const bool packed = !(getenv("PPF_ATTN_FWD_PACKED") && atoi(getenv("PPF_ATTN_FWD_PACKED")) == 0);     // 0: the per-element softmax everywhere (A/B)
     if (N <= 96) {
-        if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, true>), grid, dim3(F16_NTHR), lds6, stream, p);
-        else hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false>), grid, dim3(F16_NTHR), lds6, stream, p);
+        if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, true, false>), grid, dim3(F16_NTHR), lds6, stream, p);
+        else if (packed && N > 80) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false, true>), grid, dim3(F16_NTHR), lds6, stream, p);
+        else hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false, false>), grid, dim3(F16_NTHR), lds6, stream, p);
     } else {
-        if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, true>), grid, dim3(F16_NTHR), lds13, stream, p);
-        else hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false>), grid, dim3(F16_NTHR), lds13, stream, p);
+        if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, true, false>), grid, dim3(F16_NTHR), lds13, stream, p);
+        else if (packed && N > 192) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false, true>), grid, dim3(F16_NTHR), lds13, stream, p);
+        else hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false, false>), grid, dim3(F16_NTHR), lds13, stream, p);
     }
     PPF_LAUNCH_CHECK();
     return 0;

@@ -88,6 +88,7 @@ struct PathProbe {
     double flops = 0.0, bytes = 0.0;
 };
 PathProbe g_path[PPF_PROBE_NTAGS];
+constexpr size_t PATH_PROBE_CAP = 4096;          // event pairs per tag (one step of the largest configuration launches < 64 per tag)
 bool g_path_on = false;
 }  // namespace
 
@@ -95,7 +96,11 @@ bool g_path_on = false;
 
 PpfProbeScope::PpfProbeScope(int tag, hipStream_t s, double flops, double bytes) : stream(s) {
     if (!g_path_on || tag < 0 || tag >= PPF_PROBE_NTAGS) return;
+    // eager launches only: an event recorded into a capturing stream becomes a graph node that hipEventElapsedTime cannot read
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
     PathProbe& pr = g_path[tag];
+    if (pr.used >= PATH_PROBE_CAP) return;             // a probe left on for a long run stops counting instead of growing without bound
     if (pr.used == pr.pool.size()) {
         hipEvent_t a = nullptr, b = nullptr;           // timing events the host reads after a device synchronise: agent scope only
         (void)hipEventCreateWithFlags(&a, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&b, hipEventDisableSystemFence);

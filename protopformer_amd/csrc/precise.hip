@@ -229,8 +229,10 @@ inline int grid_for(int64_t work) {
 
 // LayerNorm backward, one wave per row r of dy; x row = row_map ? row_map[r] : r (mean / rstd recomputed from x as the forward did):
 //   dx_out[xrow] = (dres_in ? dres_in[xrow] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dw += dy * xhat, db += dy (atomics)
+// dres_in and dx_out MAY be the same buffer (every element is read, then written, by the same lane): neither is __restrict__.  dw / db may be
+// NULL (a frozen LayerNorm: requires_grad = False).
 __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ row_map,
-                                                         const float* __restrict__ w, const float* __restrict__ dres_in, float* __restrict__ dx_out,
+                                                         const float* __restrict__ w, const float* dres_in, float* dx_out,
                                                          float* __restrict__ dw, float* __restrict__ db, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
     for (int c = lane; c < D; c += 64) {
         const float xh = (src[c] - mean) * rstd, gg = g[c] * w[c];
         dx_out[xr * D + c] = (dres_in ? dres_in[xr * D + c] : 0.f) + rstd * (gg - c1 - xh * c2);
-        atomicAdd(dw + c, g[c] * xh);
-        atomicAdd(db + c, g[c]);
+        if (dw) atomicAdd(dw + c, g[c] * xh);
+        if (db) atomicAdd(db + c, g[c]);
     }
 }
 
@@ -274,13 +276,25 @@ __global__ __launch_bounds__(256) void ew_bwd_f32_kernel(int kind, const float* 
     }
 }
 
-// out[n] += sum_m in[m][n]  (bias gradients; one thread per column, rows in order)
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+// out[n] += sum_m in[m][n]  (bias gradients).  A 1024-thread workgroup owns 32 columns: 32 row groups each add every 32nd row (128-byte
+// segments, eight independent loads in flight per lane), the 32 group sums are added in a fixed order through LDS -- deterministic, and
+// M / 32 sequential loads per lane instead of M (the bottleneck head's B k = 10 496 rows: advice r5).
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* in, float* out, int M, int N) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, n = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += in[(size_t)m * N + n];
-    out[n] += s;
+    if (n < N) {
+#pragma unroll 8
+        for (int m = g; m < M; m += 32) s += in[(size_t)m * N + n];
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][cl];
+        out[n] += t;
+    }
 }
 
 // Backward of attn_f32_kernel: one workgroup per (sample, head).  Phase 1: thread q owns query row q -- probabilities p (the eps form),
@@ -588,7 +602,7 @@ __global__ __launch_bounds__(256) void class_attn_bwd_f32_kernel(const float* __
 // ---- fp32 backward of the verification mode (DeiT; tests/test_gpu_precise.py holds grad/* of the reference fixtures to 1e-3 with it) ----
 int ppf_layernorm_bwd_f32(const float* dy, const float* x, const int* row_map, const float* w, const float* dres_in, float* dx_out, float* dw, float* db,
                           int rows, int D, float eps, hipStream_t stream) {
-    PPF_CHECK_ARG(dy && x && w && dx_out && dw && db && rows > 0 && D > 0, PPF_ERR_ARG, "ppf_layernorm_bwd_f32: bad arguments");
+    PPF_CHECK_ARG(dy && x && w && dx_out && rows > 0 && D > 0, PPF_ERR_ARG, "ppf_layernorm_bwd_f32: bad arguments");
     hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dy, x, row_map, w, dres_in, dx_out, dw, db, rows, D, eps);
     PPF_LAUNCH_CHECK();
     return 0;
@@ -605,7 +619,7 @@ int ppf_ew_bwd_f32(int kind, const float* a, const float* b, float* out, const f
 
 int ppf_colsum_f32(const float* in, float* out, int M, int N, hipStream_t stream) {
     PPF_CHECK_ARG(in && out && M > 0 && N > 0, PPF_ERR_ARG, "ppf_colsum_f32: bad arguments");
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, in, out, M, N);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 31) / 32), dim3(1024), 0, stream, in, out, M, N);
     PPF_LAUNCH_CHECK();
     return 0;
 }

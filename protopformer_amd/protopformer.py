@@ -133,7 +133,8 @@ class ProtoLayerFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         # training keeps ONE (B,P,k) map: the backward takes d act / d dist from the activations themselves (ppf_proto_bwd map_is_act), so the
         # distance map (166 MB at config 3) is only written when the caller asks for it (eval / push)
-        keep_dist = need_bwd and _KEEP_DIST
+        # (k == 1: the pooled branch degenerates to one token and takes the single-token backward, which reads the distance map)
+        keep_dist = need_bwd and (_KEEP_DIST or k == 1)
         act_l, argmax, dist, act_full = ops.proto_fwd(f, 1, k, pl, act_kind, ppnet.epsilon, want_dist=keep_dist or want_dist, want_act=True)
         act_g, _, dist_g, _ = ops.proto_fwd(f, 0, 1, pg, act_kind, ppnet.epsilon, want_dist=need_bwd, want_act=False)
         ctx.set_materialize_grads(False)

@@ -89,38 +89,58 @@ def test_micro_deit_eval_train_against_reference_fixture():
     assert not bad, f"gradient direction mismatch vs reference: {bad}"
 
 
-def test_bottleneck_chain_matches_fp32_chain():
+@pytest.mark.parametrize("shape", ["micro", "deit_small"])
+def test_bottleneck_chain_matches_fp32_chain(shape):
     """backbone.addon_fwd / addon_bwd (first convolution on the bf16 MFMA GEMM, fp32 tail) against the all-fp32 chain of the verification mode
     on a bf16-representable input: outputs and saved activations to bf16 rounding; the backward evaluated with the SAME ReLU gates
-    (the product's activations) to the rounding of its bf16 result -- parameter gradients of the tail included."""
+    (the product's activations) to the rounding of its bf16 result -- parameter gradients of the tail included.
+    'deit_small' (round 6): the REAL shape of the reference's default head on BASELINE's backbone -- D = 384 -> 192 -> 192 -> 96 -> 96 -> 64 -> 64
+    (protopformer.py:90-107 with prototype_shape (2000, 64, 1, 1)) on the 128 x (1 + 81) = 10 496 rows of a batch-128 step."""
     from helpers import build_micro
     from protopformer_amd import backbone, ops, precise
-    sd, cfg, z = micro("micro_deit_bottleneck.npz")
-    m = build_micro(cfg, sd).train()
+    g = torch.Generator().manual_seed(0)
+    if shape == "micro":
+        sd, cfg, z = micro("micro_deit_bottleneck.npz")
+        m = build_micro(cfg, sd).train()
+        rows, D, widths = 40, 64, [(40, 32), (40, 32), (40, 16)]
+    else:
+        from protopformer_amd.protopformer import construct_PPNet
+        torch.manual_seed(3)
+        m = construct_PPNet("deit_small_patch16_224", pretrained=False, prototype_shape=(2000, 64, 1, 1), num_classes=200, reserve_layers=[11],
+                            reserve_token_nums=[81], use_global=True, use_ppc_loss=True, global_proto_per_class=10,
+                            add_on_layers_type="bottleneck").cuda().train()
+        rows, D = 128 * 82, 384
+        widths = [(rows, 192), (rows, 192), (rows, 96), (rows, 96), (rows, 64)]
+        with torch.no_grad():                                  # biases off zero so that their gradients and the ReLU gates matter
+            for c in backbone.addon_convs(m):
+                c.bias.copy_(0.1 * torch.randn(c.bias.shape, generator=g))
     store = m.flat_store()
     store.refresh_bf16()
-    g = torch.Generator().manual_seed(0)
-    nf16 = torch.randn(40, 64, generator=g).cuda().bfloat16()
+    nf16 = torch.randn(rows, D, generator=g).cuda().bfloat16()
     f_p, acts_p = backbone.addon_fwd(m, store, nf16)
     f_r, acts_r = precise._addon_fwd(m, nf16.float())
     assert rel_err(f_p, f_r) < 2e-3 and all(rel_err(a, b) < 4e-3 for a, b in zip(acts_p, acts_r)), (rel_err(f_p, f_r), [rel_err(a, b) for a, b in zip(acts_p, acts_r)])
-    assert len(acts_p) == 3 and [tuple(a.shape) for a in acts_p] == [(40, 32), (40, 32), (40, 16)]
-    df = torch.randn(40, 16, generator=g).cuda()
+    assert [tuple(a.shape) for a in acts_p] == widths
+    df = torch.randn(f_p.shape, generator=g).cuda()
     convs = backbone.addon_convs(m)
+    assert len(convs) == len(widths) + 1
     store.attach_all_grads()
     for c in convs:
         ops.zero_(store.grad_view(c.weight)); ops.zero_(store.grad_view(c.bias))
     dz = backbone.addon_bwd(m, store, dict(chain=acts_p), f_p, df)
     got = {i: (store.grad_view(c.weight).clone(), store.grad_view(c.bias).clone()) for i, c in enumerate(convs)}
-    # the fp32 chain backward on the same activations (torch, fp32)
-    d = df * f_p * (1 - f_p)
-    for j in (3, 2, 1):
-        w = convs[j].weight.detach().reshape(convs[j].out_channels, -1)
-        assert_close(got[j][0].reshape(w.shape), d.t() @ acts_p[j - 1], rtol=1e-4, atol=1e-5 * float((d.t() @ acts_p[j - 1]).abs().max()), what=f"tail weight gradient {j}")
-        assert_close(got[j][1], d.sum(0), rtol=1e-4, atol=1e-5 * float(d.sum(0).abs().max()), what=f"tail bias gradient {j}")
+    # the fp32 chain backward on the same activations (torch, fp64 accumulation as the referee of two fp32 summation orders over `rows`)
+    at = 1e-5 if shape == "micro" else 1e-4
+    d = (df * f_p * (1 - f_p)).double()
+    for j in reversed(range(1, len(convs))):
+        w = convs[j].weight.detach().reshape(convs[j].out_channels, -1).double()
+        wg = d.t() @ acts_p[j - 1].double()
+        assert_close(got[j][0].reshape(w.shape).double(), wg, rtol=1e-4, atol=at * float(wg.abs().max()), what=f"tail weight gradient {j}")
+        assert_close(got[j][1].double(), d.sum(0), rtol=1e-4, atol=at * float(d.sum(0).abs().max()), what=f"tail bias gradient {j}")
         d = (d @ w) * (acts_p[j - 1] > 0)
-    assert_close(got[0][1], d.sum(0), rtol=1e-4, atol=1e-5 * float(d.sum(0).abs().max()), what="first bias gradient")
-    assert_close(dz.float(), d, rtol=4e-3, atol=4e-3 * float(d.abs().max()), what="gradient w.r.t. the first pre-activation (bf16)")
+    assert_close(got[0][1].double(), d.sum(0), rtol=1e-4, atol=at * float(d.sum(0).abs().max()), what="first bias gradient")
+    assert_close(dz.double(), d, rtol=4e-3, atol=4e-3 * float(d.abs().max()), what="gradient w.r.t. the first pre-activation (bf16)")
+    report(f"bottleneck_chain_{shape}", f=rel_err(f_p, f_r), dz=rel_err(dz.float(), d.float()))
 
 
 def test_micro_deit_bottleneck_head_product_path_against_reference_fixture():

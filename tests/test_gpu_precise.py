@@ -115,22 +115,65 @@ def test_precise_baseline_heads_vs_oracle(arch, k, layer, C, gpc, P, Dp):
     m.precise = True
     for blk in m.features.blocks:
         blk.drop_path_rate = 0.0
-    img = torch.randn(2, 3, 224, 224, generator=g); label = torch.tensor([3, C - 1])
+    label = torch.tensor([3, C - 1])
+    # tie-free at the top-k boundary BY CONSTRUCTION (as tests/golden/make_golden.py does for the fixtures): of 32 drawn images take the one whose
+    # k-th and (k+1)-th largest cls_token_attn entries (oracle) are separated most (> 2e-5 of the map's maximum required): the index assert is unconditional
     with torch.no_grad():
+        best = None
+        for _try in range(32):                                    # the best-separated of 32 draws (0.1-0.2 s of oracle each)
+            img_t = torch.randn(2, 3, 224, 224, generator=g)
+            out_t = O.ppnet_forward(sd, img_t, cfg, train=True)
+            srt = out_t["cls_token_attn"].sort(dim=-1, descending=True)[0]
+            gap_t = float((srt[:, k - 1] - srt[:, k]).min()) / float(srt.max())
+            if best is None or gap_t > best[0]:
+                best = (gap_t, img_t, out_t)
+        gap, img, out = best
+        # (fp32 mode vs oracle agree to ~1e-6 per kernel; CaiT's boundary sits in the dense part of the map -- 121 of 196 tokens -- so its
+        #  best gap is ~5e-5, DeiT's ~1e-3)
+        assert gap > 2e-5, f"no tie-free input in 32 draws (best boundary gap {gap:.2e} of the maximum)"
         logits, aux = m(img.cuda())
         ce = CrossEntropyLoss()(logits, label.cuda())
         cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label.cuda())
-        out = O.ppnet_forward(sd, img, cfg, train=True)
         _, parts = O.train_loss(out, label, cfg, with_ppc=True)
     # the rollout zeroes the 90 % smallest entries of every layer's map: an entry within fp32 rounding of that threshold is kept by one
     # implementation and dropped by the other, so after 11 / 25 layers a handful of outputs differ at the 1e-3 level (relative to the
     # row maximum) although every kernel is exact to 1e-6 -- gate the map at 5e-3 of its maximum, everything downstream at 1e-3
     assert rel_err(aux[3], out["cls_token_attn"]) < 5e-3, rel_err(aux[3], out["cls_token_attn"])
-    srt = out["cls_token_attn"].sort(dim=-1, descending=True)[0]
-    if float((srt[:, k - 1] - srt[:, k]).min()) > 1e-5 * float(srt.max()):          # tie-free at the boundary: indices must be exact
-        assert torch.equal(m._ppc_cache[1].cpu().long(), out["reserve_idx"])
+    assert torch.equal(m._ppc_cache[1].cpu().long(), out["reserve_idx"])            # bit-exact reservation (north_star), unconditional
     assert rel_err(logits, out["logits"]) < TOL, rel_err(logits, out["logits"])
     assert_elementwise(logits, out["logits"], TOL, "fp32 mode logits, real head")
     assert rel_err(ce, parts["ce"]) < TOL and rel_err(cov, parts["ppc_cov"]) < TOL and rel_err(mean, parts["ppc_mean"]) < TOL
     far = out["distances"] >= 0.05
     assert_close(aux[2].cpu()[far], out["total_proto_act"][far], rtol=TOL, atol=1e-5, what="total_proto_act (d >= 0.05)")
+
+
+def test_single_reserved_token_trains():
+    """reserve_token_nums=[1] (k = 1 passes the reference's perfect-square assert): the pooled branch degenerates to ONE token, whose backward
+    reads the distance map -- round-5 advice: ProtoLayerFn saved only the activation map and this configuration stopped training.  fp32 mode
+    forward + backward against autograd of the oracle at 1e-3 on the micro DeiT weights."""
+    from protopformer_amd.protopformer import CrossEntropyLoss
+    sd, cfg, z = micro("micro_deit.npz")
+    cfg = dict(cfg, reserve_k=1)
+    m = build_micro(cfg, sd)
+    m.precise = True
+    m.train()
+    img, label = torch.from_numpy(z["img"]), torch.from_numpy(z["label"])
+    logits, aux = m(img.cuda())
+    ce = CrossEntropyLoss()(logits, label.cuda())
+    cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], label.cuda())
+    (ce + 0.1 * cov + 0.5 * mean).backward()
+    params = {k: v.clone().requires_grad_(k not in O.FROZEN_KEYS) for k, v in sd.items()}
+    out = O.ppnet_forward(params, img, cfg, train=True)
+    assert torch.equal(m._ppc_cache[1].cpu().long(), out["reserve_idx"])
+    loss_ref, parts = O.train_loss(out, label, cfg, with_ppc=True)
+    (parts["ce"] + 0.1 * parts["ppc_cov"] + 0.5 * parts["ppc_mean"]).backward()
+    assert rel_err(logits, out["logits"]) < TOL and rel_err(ce, parts["ce"]) < TOL
+    n = 0
+    for name, p in m.named_parameters():
+        ref = params[name].grad
+        if not p.requires_grad or ref is None or float(ref.abs().max()) < 1e-7:
+            continue
+        assert p.grad is not None, name
+        assert_elementwise(p.grad.detach().float().cpu().reshape(-1), ref.reshape(-1), TOL, f"k=1 grad/{name}")
+        n += 1
+    assert n >= 20, n
