@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ppf_stream_t; /* == hipStream_t */
 
 /* Bumped whenever an entry point changes its parameter list or meaning.  ppf_abi_version() returns the value the library was built
  * with; the binding (protopformer_amd/_lib.py EXPECTED_ABI) refuses a library of another version instead of shifting arguments. */
-#define PPF_ABI_VERSION 9
+#define PPF_ABI_VERSION 10
 
 /* ---- runtime ------------------------------------------------------------------------------------------------- */
 const char* ppf_last_error(void);
@@ -304,6 +304,9 @@ int ppf_axpbypcz(const float* x, const float* y, const float* z, float* out, flo
 
 /* ---- streaming kernels -------------------------------------------------------------------------------------------- */
 int ppf_cast_f32_bf16(const float* in, void* out, int64_t n, ppf_stream_t stream);
+/* bf16 -> fp32 (exact; n % 8 == 0): the optional bf16 wire format of the gradient all-reduce (engine.GradSync payload='bf16';
+ * replaces nothing in the reference -- main.py:369-371 exchanges fp32 through DistributedDataParallel) */
+int ppf_cast_bf16_f32(const void* in, float* out, int64_t n, ppf_stream_t stream);
 /* PatchEmbed unfold (timm PatchEmbed conv k=s=patch, deit:174): img [B][C][H][W] -> cols bf16 [B*gh*gw][C*p*p] */
 int ppf_im2col_patch(const float* img, void* cols, int B, int C, int H, int W, int patch, ppf_stream_t stream);
 /* cls token + position embedding (deit:176-178 lead=1; cait:307-309 lead=0) and its backward */

@@ -33,6 +33,7 @@ SIGS = {
     "ppf_layernorm_bwd": "pppppp" "pppp" "pp" "i" "pppp" "ii" "pz" "s",
     "ppf_layernorm_bwd_reduce": "p" "ii" "pppp" "s",
     "ppf_cast_f32_bf16": "ppls",
+    "ppf_cast_bf16_f32": "ppls",
     "ppf_im2col_patch": "ppiiiiis",
     "ppf_assemble_tokens": "ppppiiiis",
     "ppf_assemble_tokens_bwd": "ppppiiiis",
@@ -92,7 +93,7 @@ SIGS = {
     "ppf_stream_wait_mark": "pl",
 }
 
-EXPECTED_ABI = 9               # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
+EXPECTED_ABI = 10              # == PPF_ABI_VERSION of include/ppf_hip.h this table was written against (tests/test_abi_cpu.py)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "L": ctypes.c_uint64, "f": ctypes.c_float, "s": ctypes.c_void_p, "z": ctypes.c_size_t}
 _lib = None

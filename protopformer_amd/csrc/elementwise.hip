@@ -11,6 +11,16 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in,
     }
 }
 
+// the inverse widening (exact): the bf16 wire format of the gradient exchange back into the fp32 gradient buffer
+__global__ __launch_bounds__(256) void widen_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const uint4 u = reinterpret_cast<const uint4*>(in)[i];
+        const float2 a = unpack_bf16x2(u.x), b = unpack_bf16x2(u.y), c = unpack_bf16x2(u.z), d = unpack_bf16x2(u.w);
+        reinterpret_cast<float4*>(out)[2 * i] = make_float4(a.x, a.y, b.x, b.y);
+        reinterpret_cast<float4*>(out)[2 * i + 1] = make_float4(c.x, c.y, d.x, d.y);
+    }
+}
+
 // img [B][C][H][W] fp32 -> cols [B*gh*gw][C*p*p] bf16, column order (c, py, px) = Conv2d weight.reshape(D,-1) order.
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, int B, int C,
                                                      int H, int W, int p, int64_t total8) {
@@ -364,6 +374,13 @@ extern "C" {
 int ppf_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream) {
     PPF_CHECK_ARG(n > 0 && (n % 8) == 0, PPF_ERR_SHAPE, "ppf_cast_f32_bf16: n=%lld must be a positive multiple of 8", (long long)n);
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, in, (bf16_t*)out, n / 8);
+    PPF_LAUNCH_CHECK();
+    return 0;
+}
+
+int ppf_cast_bf16_f32(const void* in, float* out, int64_t n, hipStream_t stream) {
+    PPF_CHECK_ARG(in && out && n > 0 && (n % 8) == 0, PPF_ERR_SHAPE, "ppf_cast_bf16_f32: n=%lld must be a positive multiple of 8", (long long)n);
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)in, out, n / 8);
     PPF_LAUNCH_CHECK();
     return 0;
 }

@@ -270,9 +270,14 @@ def create_scheduler(args, optimizer):
 
 
 class GradSync:
-    """Chunked all-reduce (sum) of a flat gradient buffer over the default process group, overlapped with backward."""
+    """Chunked all-reduce (sum) of a flat gradient buffer over the default process group, overlapped with backward.
 
-    def __init__(self, flat_grads, chunk_bounds, use_side_stream=True):
+    payload='bf16' (or PPF_GRADSYNC_BF16=1): the chunks travel as bf16 -- half the link bytes (46.7 instead of 93.4 MB per step at
+    deit_small) for one rounding of every SUMMAND and of every partial sum on the wire (relative 2^-9 each; the fp32 buffer receives the
+    widened result).  Narrowing / widening run on the communication stream (ppf_cast_f32_bf16 / ppf_cast_bf16_f32), so they cost HBM
+    traffic (3 x the chunk) but no compute-stream time.  The reference exchanges fp32 (DistributedDataParallel, main.py:369-371): default."""
+
+    def __init__(self, flat_grads, chunk_bounds, use_side_stream=True, payload=None):
         self.g = flat_grads
         self.bounds = list(chunk_bounds)                      # ascending element offsets; chunk c = [bounds[c], bounds[c+1])
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -282,6 +287,43 @@ class GradSync:
         self.pending = []
         self.guard = None                                     # the loss summed over the ranks (reduce_guard)
         self.launched = 0                                     # collectives issued so far (tests: the forced single-rank path really ran)
+        if payload is None:
+            payload = "bf16" if os.environ.get("PPF_GRADSYNC_BF16", "0") != "0" else "fp32"
+        if payload not in ("fp32", "bf16"):
+            raise ValueError(f"GradSync payload must be 'fp32' or 'bf16', got {payload!r}")
+        self.payload = payload
+        self.wire = torch.empty(flat_grads.numel(), dtype=torch.bfloat16, device=flat_grads.device) if payload == "bf16" else None
+
+    def _narrow(self, lo, hi):
+        if self.cuda:
+            _lib.call("ppf_cast_f32_bf16", self.g[lo:hi], self.wire[lo:hi], hi - lo)      # (on the override stream pushed by the caller)
+        else:
+            self.wire[lo:hi].copy_(self.g[lo:hi])
+
+    def _widen(self, lo, hi):
+        if self.cuda:
+            _lib.call("ppf_cast_bf16_f32", self.wire[lo:hi], self.g[lo:hi], hi - lo)
+        else:
+            self.g[lo:hi].copy_(self.wire[lo:hi])
+
+    def _exchange(self, lo, hi):
+        """The collective of one chunk on the CURRENT torch stream (the communication stream when there is one)."""
+        if self.wire is None:
+            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            return
+        if self.cuda and (lo % 8 or hi % 8):
+            raise ValueError("GradSync bf16 payload: chunk bounds must be multiples of 8 elements (FlatStore segments are)")
+        raw = torch.cuda.current_stream().cuda_stream if self.cuda else None
+        if raw is not None:
+            _lib.push_stream(raw)
+        try:
+            self._narrow(lo, hi)
+            w = dist.all_reduce(self.wire[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            w.wait()                                          # NCCL: the current stream waits (no host block); gloo: the host waits
+            self._widen(lo, hi)
+        finally:
+            if raw is not None:
+                _lib.pop_stream()
 
     def chunk_ready(self, c, also=()):
         """Launch the all-reduce of chunk c: every kernel that writes it has been enqueued on the current stream or on one of
@@ -292,7 +334,6 @@ class GradSync:
         lo, hi = self.bounds[c], self.bounds[c + 1]
         if hi <= lo:
             return
-        view = self.g[lo:hi]
         self.launched += 1
         if self.stream is not None:
             evs = []
@@ -303,12 +344,12 @@ class GradSync:
             with torch.cuda.stream(self.stream):
                 for ev in evs:
                     self.stream.wait_event(ev)
-                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                self._exchange(lo, hi)
         else:
             for st in also:
                 if st is not None:
                     torch.cuda.current_stream().wait_stream(st)
-            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self._exchange(lo, hi)
 
     def reduce_guard(self, loss):
         """The device-side non-finite stop (ppf_adamw_step_guarded) must take the same decision on every rank: returns a copy of the loss
@@ -362,31 +403,52 @@ def broadcast_replica_state(ppnet, optimizer=None, src=0):
     st.invalidate()
 
 
-def make_grad_sync(ppnet, optimizer=None, n_chunks=4):
-    """Chunk the flat gradient in backward-completion order: [heads+norm | late blocks | ... | early blocks+embedding], after
-    making the replicas identical (rank-0 broadcast of parameters, frozen tensors and optimizer state)."""
+def readiness_cuts(depth):
+    """Blocks at which a new gradient chunk starts.  Backward completes the blocks depth-1 .. 0, and the weight-gradient lane lags the
+    main chain, so what becomes ready LAST is what the optimizer waits for: the chunks shrink geometrically towards block 0
+    (depth 12 -> cuts {1, 2, 4, 8}: [b8..b11] | [b4..b7] | [b2, b3] | [b1] | [embedding + b0]) -- the exchange of the large early chunks hides
+    under the rest of backward and the exposed tail is one block + the embedding (8.6 of 93.4 MB at deit_small)."""
+    cuts, c = [], 1
+    while c < depth:
+        cuts.append(c)
+        c *= 2
+    return cuts
+
+
+def make_grad_sync(ppnet, optimizer=None, n_chunks=None, cuts=None, payload=None):
+    """Chunk the flat gradient in backward-completion order: [heads + norm | late blocks | ... | block 1 | embedding + block 0], after making
+    the replicas identical (rank-0 broadcast of parameters, frozen tensors and optimizer state).
+    cuts: block indices that start a chunk (default readiness_cuts(depth); PPF_GRADSYNC_CUTS="8,4" overrides); n_chunks: the pre-round-6
+    equal partition into n_chunks - 1 block groups (kept for A/B)."""
     ppnet = _unwrap(ppnet)
     broadcast_replica_state(ppnet, optimizer)
     st = ppnet.flat_store()
-    block_offsets = []
-    for name, p, o, n in st.entries:
-        if name.startswith("features.blocks.") and name.split(".")[3] == "norm1" and name.endswith("weight"):
-            block_offsets.append(o)
-    depth = len(block_offsets)
-    per = max(1, math.ceil(depth / max(1, n_chunks - 1)))
-    cuts = sorted({block_offsets[i] for i in range(0, depth, per)})
-    norm_off = next(o for name, p, o, n in st.entries if name == "features.norm.weight")
-    bounds = [0] + [c for c in cuts if c > 0] + [norm_off, st.total]
-    bounds = sorted(set(bounds))
-    sync = GradSync(st.grads, bounds)
-    # chunk index that becomes complete when block i's backward has been enqueued
-    sync.block_chunk = {}
-    for i, off in enumerate(block_offsets):
-        if off in bounds and off != 0:
-            sync.block_chunk[i] = bounds.index(off)
+    env = os.environ.get("PPF_GRADSYNC_CUTS")
+    if cuts is None and env:
+        cuts = [int(v) for v in env.split(",") if v.strip()]
+    bounds, block_chunk = chunk_plan([(name, o) for name, p, o, n in st.entries], st.total, cuts=cuts, n_chunks=n_chunks)
+    sync = GradSync(st.grads, bounds, payload=payload)
+    sync.block_chunk = block_chunk                    # chunk that becomes complete when block i's backward has been enqueued (it STARTS at block i)
     sync.tail_chunk = len(bounds) - 2                 # final norm + add-on + prototypes: ready first
-    sync.head_chunk = 0                               # embedding + first blocks: ready last
+    sync.head_chunk = 0                               # embedding + block 0 (.. first cut): ready last
     return sync
+
+
+def chunk_plan(entries, total, cuts=None, n_chunks=None):
+    """(bounds, block_chunk) of the flat gradient buffer whose segments are `entries` = [(parameter name, element offset)] in flat order
+    ([embedding | blocks 0 .. depth-1 | (class-attention blocks) | final norm + heads]): ascending chunk bounds and {block index that starts a
+    chunk: chunk index}.  Pure (tests/test_dist_cpu.py)."""
+    block_offsets = [o for name, o in entries if name.startswith("features.blocks.") and name.split(".")[3] == "norm1" and name.endswith("weight")]
+    depth = len(block_offsets)
+    if cuts is None and n_chunks is not None:
+        per = max(1, math.ceil(depth / max(1, n_chunks - 1)))
+        cuts = list(range(per, depth, per))
+    if cuts is None:
+        cuts = readiness_cuts(depth)
+    cuts = sorted({int(c) for c in cuts if 0 < int(c) < depth})
+    norm_off = next(o for name, o in entries if name == "features.norm.weight")
+    bounds = sorted({0, norm_off, total} | {block_offsets[c] for c in cuts})
+    return bounds, {i: bounds.index(block_offsets[i]) for i in cuts}
 
 
 def _forward_backward(model, criterion, samples, targets, optimizer, epoch, ppc_cov_coe, ppc_mean_coe, use_ppc_loss, grad_sync, check_finite,

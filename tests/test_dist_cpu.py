@@ -32,6 +32,16 @@ def _worker(rank, world, port, q):
     ok = ok and abs(float(good) - sum(1.5 + r for r in range(world))) < 1e-6
     bad = sync.reduce_guard(torch.tensor(float("nan") if rank == 1 else 2.0)); sync.finish()
     ok = ok and not bool(torch.isfinite(bad).all()) and bad.data_ptr() == good.data_ptr()
+    # bf16 wire format (round 6): same chunks, each summand and the sum rounded once to bf16 -> the fp32 buffer holds the widened result,
+    # within 2 bf16 roundings (2 x 2^-9 relative) of the fp32 exchange, and EXACTLY bf16(bf16(a) + bf16(b)) for two ranks
+    g16 = mine.clone()
+    s16 = GradSync(g16, [0, 128, 640, 1000], use_side_stream=False, payload="bf16")
+    for c in (2, 1, 0):
+        s16.chunk_ready(c)
+    ok = ok and s16.finish() == 1.0 / world and s16.payload == "bf16" and s16.launched == 3
+    exact = sum(t.bfloat16().float() for t in gathered).bfloat16().float()
+    ok = ok and torch.equal(g16, exact)
+    ok = ok and bool(((g16 - expect).abs() <= 2 ** -7 * expect.abs() + 2 ** -8 * max(t.abs().max() for t in gathered)).all())
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -57,3 +67,24 @@ def test_grad_sync_single_process_is_noop():
     assert s.finish() == 1.0 and torch.equal(g, torch.arange(10.0))
     loss = torch.tensor(3.0)
     assert s.reduce_guard(loss).data_ptr() == loss.data_ptr() and s.launched == 0          # single rank: the loss itself, no collective
+
+
+def test_chunk_plan_orders_by_readiness():
+    """make_grad_sync's chunk boundaries (engine.chunk_plan, pure): chunks shrink towards block 0, which backward finishes last -- the
+    exposed tail of the exchange is [embedding + block 0], the first chunk to go is [final norm + heads]."""
+    from protopformer_amd.engine import chunk_plan, readiness_cuts
+    assert readiness_cuts(12) == [1, 2, 4, 8] and readiness_cuts(24) == [1, 2, 4, 8, 16] and readiness_cuts(2) == [1] and readiness_cuts(1) == []
+    ents, off = [("features.cls_token", 0), ("features.pos_embed", 8), ("features.patch_embed.proj.weight", 100)], 1000
+    for i in range(12):
+        ents += [(f"features.blocks.{i}.norm1.weight", off), (f"features.blocks.{i}.attn.qkv.weight", off + 8)]
+        off += 1000
+    ents += [("features.norm.weight", off), ("prototype_vectors", off + 16)]
+    bounds, block_chunk = chunk_plan(ents, off + 500)
+    assert bounds == [0, 2000, 3000, 5000, 9000, 13000, 13500]
+    assert block_chunk == {1: 1, 2: 2, 4: 3, 8: 4}               # block i done -> the chunk that starts at block i is complete
+    sizes = [b - a for a, b in zip(bounds, bounds[1:])]
+    assert sizes[1:5] == sorted(sizes[1:5])                       # block chunks grow with the block index: the last ready is the smallest
+    b4, bc4 = chunk_plan(ents, off + 500, n_chunks=4)             # the pre-round-6 equal partition, kept for A/B
+    assert b4 == [0, 5000, 9000, 13000, 13500] and bc4 == {4: 1, 8: 2}
+    b2, bc2 = chunk_plan(ents, off + 500, cuts=[6, 0, 12, 99])    # out-of-range cuts are dropped
+    assert b2 == [0, 7000, 13000, 13500] and bc2 == {6: 1}

@@ -119,8 +119,21 @@ def test_bottleneck_chain_matches_fp32_chain(shape):
     nf16 = torch.randn(rows, D, generator=g).cuda().bfloat16()
     f_p, acts_p = backbone.addon_fwd(m, store, nf16)
     f_r, acts_r = precise._addon_fwd(m, nf16.float())
-    assert rel_err(f_p, f_r) < 2e-3 and all(rel_err(a, b) < 4e-3 for a, b in zip(acts_p, acts_r)), (rel_err(f_p, f_r), [rel_err(a, b) for a, b in zip(acts_p, acts_r)])
+    # against the all-fp32 chain the difference is the bf16 rounding of the FIRST convolution's weight (2^-9 per element: 1.6e-3 of the
+    # first activation's maximum at K = 384), carried through the tail: measured f 9.4e-3 at the real shape (five more layers), 1e-3 micro
+    tol_f, tol_a = (2e-3, 4e-3) if shape == "micro" else (3e-2, 8e-3)
+    assert rel_err(f_p, f_r) < tol_f and all(rel_err(a, b) < tol_a for a, b in zip(acts_p, acts_r)), (rel_err(f_p, f_r), [rel_err(a, b) for a, b in zip(acts_p, acts_r)])
     assert [tuple(a.shape) for a in acts_p] == widths
+    # ... and against the SAME arithmetic in fp64 (first convolution on the bf16-rounded weight the MFMA GEMM reads, fp32 weights after it): what
+    # is left is fp32 accumulation order -- the kernels themselves at 1e-4
+    cv = backbone.addon_convs(m)
+    w2 = lambda c_: c_.weight.detach().reshape(c_.out_channels, -1)
+    h64 = torch.relu(nf16.double() @ w2(cv[0]).bfloat16().double().t() + cv[0].bias.detach().double())
+    for j, c_ in enumerate(cv[1:]):
+        assert rel_err(acts_p[j], h64.float()) < 1e-4, (j, rel_err(acts_p[j], h64.float()))
+        h64 = h64 @ w2(c_).double().t() + c_.bias.detach().double()
+        h64 = torch.sigmoid(h64) if j == len(cv) - 2 else torch.relu(h64)            # protopformer.py:90-107: ReLU after every convolution but the last
+    assert rel_err(f_p, h64.float()) < 1e-4, rel_err(f_p, h64.float())
     df = torch.randn(f_p.shape, generator=g).cuda()
     convs = backbone.addon_convs(m)
     assert len(convs) == len(widths) + 1
