@@ -353,15 +353,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path)")
     cfg = dict(CONFIGS[args.config])
     batch = args.batch or cfg["batch"]
-    # test-only: PPF_BENCH_ONE_GPU=1 puts every rank on cuda:0 and PPF_BENCH_BACKEND=gloo swaps the process-group backend, so that the whole
+    # test-only: PPF_BENCH_ONE_GPU=1 puts every rank on cuda:0 and makes gloo the process-group backend, so that the whole
     # multi-rank flow of this file (broadcast, chunked all-reduce, guard, replay with live collectives, probe legs) runs on a 1-GPU box
     # (scripts/gpu/bench_two_ranks_check.sh: ~10 s per step through gloo, too slow for the test suite); RCCL itself refuses two ranks on one device
     if os.environ.get("PPF_BENCH_ONE_GPU", "0") != "0":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if os.environ.get("PPF_MAIN_PRIORITY"):
-        # A/B: run the main chain on a HIP stream of the given priority (-1 = high; the weight-gradient lane stays at the default)
-        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["PPF_MAIN_PRIORITY"])))
     if args.wgrad_alone:
         print(json.dumps(wgrad_uncontended(cfg, batch, torch.device("cuda", local_rank))), flush=True)
         return
@@ -369,7 +366,7 @@ def main():
     if world > 1 or os.environ.get("PPF_FORCE_GRADSYNC", "0") != "0":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("PPF_BENCH_BACKEND", "nccl")
+        backend = "gloo" if os.environ.get("PPF_BENCH_ONE_GPU", "0") != "0" else "nccl"
         if backend == "nccl":
             dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=device)
         else:
@@ -493,7 +490,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{cfg['arch']}, synthetic 224x224, {cfg['P']}x{cfg['Dp']} prototypes, {cfg['C']} classes, k={cfg['k']}, batch {batch}/GPU "
                                    f"({cfg['label']}), train step = fwd+CE+PPC+bwd+allreduce+AdamW+EMA, DropPath 0.1; blocks after the token "
-                                   "reservation run compacted on the 1+k reserved rows (equal to the masked full-length blocks to bf16 rounding)",
+                                   "reservation run compacted on the 1+k reserved rows (equal to the masked full-length blocks to bf16 rounding); "
+                                   "bf16 backbone: the reserved tokens differ from the fp32 reference's in ~2-3 % of positions (any bf16 rounding upstream "
+                                   "of the rollout's 90 % discard does that: profiles/r6_reserve_precision.txt; PPNet.precise = fp32 mode, bit-exact)",
                        "global_batch": world * batch, "parallelism": f"dp{world}", "execution": graph_note},
             "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
             "rccl_backend": dist.get_backend() if dist.is_initialized() else None,

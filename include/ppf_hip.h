@@ -65,6 +65,9 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
  * in the L2 / memory-side cache); its first 16 KiB are a reserved prefix (the arrival counters of round 3's in-kernel reduce, deleted). */
 size_t ppf_gemm_workspace_bytes(int M, int N, int K);
 
+/* Test hook (tests/test_gpu_gemm.py): force = 1 sends every shape the 224 x 128 NT kernel can legally take to it, 0 = the cost model. */
+int ppf_gemm_test_force_g224(int force);
+
 /* Roofline probe of the split-K weight-gradient kernel (epi 6 with a workspace): HIP events (from a reused pool) on the launch
  * stream around the kernel itself.  ppf_gemm_probe(1) clears and starts, (0) stops, (2) stops and destroys the pool;
  * ppf_gemm_probe_read synchronises the events and returns the summed kernel time, the launch count and the algorithmic
@@ -103,18 +106,6 @@ int ppf_th_attn_bwd_f32(const float* qkv, const float* dout, const float* wl, co
                         float* dwl, float* dbl, float* dww, float* dbw, int B, int H, int N, int D, ppf_stream_t stream);
 int ppf_class_attn_bwd_f32(const float* q, const float* k, const float* v, const float* policy, const float* dout, float* dq, float* dk, float* dv,
                            int B, int H, int N1, int D, ppf_stream_t stream);
-
-/* ---- fused MLP forward (csrc/mlpfwd.hip, round 5): timm Mlp + residual + the following LayerNorm in one launch -------------------
- * `x = x + drop_path(mlp(norm2(x)))` then the next norm (deit:76-81; cait:153-157 with colscale = gamma_2):
- *   h = gelu(A W1^T + b1)  bf16 [M][hid]  and  dgelu = gelu'(A W1^T + b1) as 8-bit codes [M][hid]   (both written for backward)
- *   xout = res + rowscale[m / rows_per_group] * colscale[n] * (h W2^T + b2)   (fp32, may alias res; aux_out optional = bf16(h W2^T + b2))
- *   ln_out = bf16(LN(xout) * ln_w + ln_b), ln_mean, ln_rstd                   (ln_out == NULL: no LayerNorm)
- * A [M][D] bf16 = the LayerNorm output feeding fc1, W1 [hid][D], W2 [D][hid] bf16 (nn.Linear layout), D in {192, 384}, hid % 64 == 0,
- * tiles of rows_per_tile <= 112 rows (one workgroup each; the activation tile stays in LDS, the hidden layer is never read back). */
-int ppf_mlp_fwd_supported(int D, int hid, int rows_per_tile);
-int ppf_mlp_fwd(const void* A, const void* W1, const float* b1, const void* W2, const float* b2, int M, int D, int hid, int rows_per_tile,
-                void* h_out, void* dgelu_out, const float* res, float* xout, const float* rowscale, int rows_per_group, const float* colscale,
-                void* aux_out, const float* ln_w, const float* ln_b, void* ln_out, float* ln_mean, float* ln_rstd, float eps, ppf_stream_t stream);
 
 /* ---- full-row GEMM with row-wise fused epilogues (csrc/rowgemm.hip) ------------------------------------------------------------
  * acc = A[M][K] . B[D][K]^T with D = the model width (192 or 384): a workgroup owns complete output rows (tiles of rows_per_tile <=
@@ -233,15 +224,6 @@ int ppf_rollout_threshold(const float* hm_layer, int B, int N, int NP, int kdrop
 int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int NP, const float* init_rows, int n_init, int lead,
                 int kdrop, int kdrop_init, float identity, int k, const void* thr_u32, float* cls_attn, int* idx, float* policy,
                 ppf_stream_t stream);
-/* The rollout split for a two-stream schedule (round 4): everything of a layer's step that does not depend on the chain -- the order
- * statistic, the discard, the row sums -- is done per layer as soon as its head-mean map exists, leaving a column-compressed record of
- * the kept entries per sample (ppf_rollout_compact_bytes(N, kdrop) bytes; 0 = form not applicable: use ppf_rollout); the chain at the
- * reservation layer then reads ~22 KB instead of the 157 KB map per layer and sample.  Same outputs as ppf_rollout up to the summation
- * order inside a column (deit_models_attn.py:99-124, 223-234; cait_models_attn.py:223-261). */
-size_t ppf_rollout_compact_bytes(int N, int kdrop);
-int ppf_rollout_compact_layer(const float* hm_layer, int B, int N, int NP, int kdrop, float identity, void* recs_layer, ppf_stream_t stream);
-int ppf_rollout_compact(const void* recs, int L, int B, int N, const float* init_rows, int n_init, int lead, int kdrop, int kdrop_init,
-                        float identity, int k, float* cls_attn, int* idx, float* policy, ppf_stream_t stream);
 /* topk(k) + ascending sort of indices on given scores [B][n] (protopformer.py:157-158, 273-274) */
 int ppf_topk_sorted(const float* scores, int B, int n, int k, int* idx, ppf_stream_t stream);
 

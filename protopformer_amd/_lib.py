@@ -23,9 +23,9 @@ SIGS = {
     "ppf_attn_bwd_f32": "ppppp" "iiiiii" "s",
     "ppf_th_attn_bwd_f32": "ppppppp" "pppp" "iiii" "s",
     "ppf_class_attn_bwd_f32": "pppppppp" "iiii" "s",
-    "ppf_mlp_fwd": "ppppp" "iiii" "pp" "pp" "pi" "p" "p" "ppppp" "f" "s",
     "ppf_transpose_bf16_batched": "ppp" "ii" "s",
     "ppf_gemm_probe": "i",
+    "ppf_gemm_test_force_g224": "i",
     "ppf_gemm_probe_read": "pppp",
     "ppf_path_probe": "i",
     "ppf_path_probe_read": "ipppp",
@@ -44,8 +44,6 @@ SIGS = {
     "ppf_attn_bwd": "pppppppp" "iiiii" "i" "s",
     "ppf_rollout": "pl" "iiii" "p" "iiii" "f" "i" "pppp" "s",
     "ppf_rollout_threshold": "p" "iiii" "p" "s",
-    "ppf_rollout_compact_layer": "p" "iiii" "f" "p" "s",
-    "ppf_rollout_compact": "p" "iii" "p" "iiii" "f" "i" "ppp" "s",
     "ppf_proto_fwd": "pliip" "iiii" "f" "pppp" "pz" "s",
     "ppf_proto_bwd": "pliip" "iiii" "f" "pi" "pppp" "l" "p" "pz" "s",
     "ppf_proto_bwd_rows": "pliip" "iiii" "f" "pi" "pp" "i" "ppp" "l" "p" "pz" "s",
@@ -121,8 +119,6 @@ def lib():
         _lib.ppf_sgemm_pair_workspace.argtypes = [ctypes.c_int] * 5
         _lib.ppf_proto_bwd_single_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_bwd_single_workspace.argtypes = [ctypes.c_int] * 3
-        _lib.ppf_rollout_compact_bytes.restype = ctypes.c_size_t
-        _lib.ppf_rollout_compact_bytes.argtypes = [ctypes.c_int] * 2
         _lib.ppf_proto_bwd_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_fwd_workspace.restype = ctypes.c_size_t
         _lib.ppf_proto_fwd_workspace.argtypes = [ctypes.c_int] * 2
@@ -135,8 +131,6 @@ def lib():
         _lib.ppf_clip_grad_blocks.argtypes = []
         _lib.ppf_rowgemm_supported.restype = ctypes.c_int
         _lib.ppf_rowgemm_supported.argtypes = [ctypes.c_int] * 3
-        _lib.ppf_mlp_fwd_supported.restype = ctypes.c_int
-        _lib.ppf_mlp_fwd_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_attn_fwd_hm_supported.restype = ctypes.c_int
         _lib.ppf_attn_fwd_hm_supported.argtypes = [ctypes.c_int] * 3
         _lib.ppf_th_fused_supported.restype = ctypes.c_int

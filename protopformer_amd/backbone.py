@@ -16,17 +16,15 @@ from .ops import EPI_ATOMIC, EPI_BF16, EPI_DGELU, EPI_F32, EPI_GELU, EPI_RESID, 
 
 LN_EPS = 1e-6
 _KEEP_CACHE = {}
-# PPF_ROWGEMM_FWD / PPF_ROWGEMM_BWD = 0 / 1: keep / use the full-row GEMMs with fused LayerNorm in the forward / backward pass (A/B).
-# Backward default "auto" (measured, profiles/r3_rowgemm.txt section 7): in the backward pass the full-row kernels own whole CUs while the
-# weight-gradient GEMMs of the side stream want to share them -- a win where the step is launch-bound (deit_tiny batch 128: +7.5 %),
-# neutral in throughput at deit_small batch 256 where it stretches the weight-gradient kernels from 100 to 137 us; so: small problems only.
-_ROW_FWD = os.environ.get("PPF_ROWGEMM_FWD", "1") != "0"
-_ROW_BWD = os.environ.get("PPF_ROWGEMM_BWD", "auto")
+# The full-row GEMMs with fused LayerNorm (csrc/rowgemm.hip) serve the forward pass wherever the shape allows; in the BACKWARD pass they own whole
+# CUs while the weight-gradient GEMMs of the side stream want to share them -- a win where the step is launch-bound (deit_tiny batch 128:
+# +7.5 %), neutral in throughput at deit_small batch 256 where they stretch the weight-gradient kernels from 100 to 137 us
+# (profiles/r3_rowgemm.txt section 7); so: small problems only.
 _ROW_BWD_MAX_ELEMS = 12_000_000          # rows x width of the residual stream up to which the backward pass uses them
 
 
 def _row_bwd(M, D):
-    return _ROW_BWD == "1" or (_ROW_BWD == "auto" and M * D <= _ROW_BWD_MAX_ELEMS)
+    return M * D <= _ROW_BWD_MAX_ELEMS
 
 
 def droppath_scales(rates, B, device, training):
@@ -87,13 +85,10 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     NP = (N + 3) // 4 * 4
     hm = torch.empty((max(reserve_layer, 1), B, N, NP), dtype=torch.float32, device=x.device)
     thr = torch.empty((max(reserve_layer, 1), B), dtype=torch.int32, device=x.device)       # rollout discard thresholds per (layer, sample)
-    side_thr = reserve_layer > 0 and os.environ.get("PPF_ROLLOUT_SIDE", "1") != "0"
-    # PPF_ROLLOUT_COMPACT=1 (round 4, opt-in): the side stream leaves each layer's processed map in column-compressed form (order statistic,
-    # discard, row sums done) and the chain at the reservation layer reads 22 KB instead of 157 KB per layer and sample: the main stream's
-    # wait for the chain shrinks from 168 to 33 us, but the heavier per-layer kernel (130 vs 71 us under the forward pass) costs the main
-    # stream more than that: deit_small 16 842 -> 16 580, cait_xxs24 10 098 -> 10 021, deit_tiny 26 641 -> 26 822 (profiles/r4_queue_gaps.txt)
-    rec_bytes = ops.rollout_compact_bytes(N) if (side_thr and os.environ.get("PPF_ROLLOUT_COMPACT", "0") != "0") else 0
-    recs = torch.empty((max(reserve_layer, 1), B, rec_bytes), dtype=torch.uint8, device=x.device) if rec_bytes else None
+    # the rollout's per-layer order statistic runs on the side stream right behind the layer's head-mean map.  (Round 4 also built a
+    # column-compressed record per layer that shrinks the main stream's wait for the chain from 168 to 33 us; its heavier per-layer kernel cost
+    # more than that -- deit_small 16 842 -> 16 580 img/s, profiles/r4_queue_gaps.txt -- and it was removed in round 6.)
+    side_thr = reserve_layer > 0
     if compact is None:
         compact = os.environ.get("PPF_COMPACT_RESERVED", "1") != "0"
     policy = None
@@ -103,7 +98,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
     x = x.reshape(B * N, D)
     lane = wgrad_lane(store)
     rolled = None                                 # rollout outputs when the chain itself ran on the side stream
-    roll_side = reserve_layer > 0 and os.environ.get("PPF_ROLLOUT_CHAIN_SIDE", "1") != "0"
+    roll_side = reserve_layer > 0
     pre = None                                    # (n1, mean1, rstd1) of the coming block when the previous block's fc2 GEMM produced them
     nblk = len(feats.blocks)
     for i, blk in enumerate(feats.blocks):
@@ -112,7 +107,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
             if rolled is not None:
                 cls_attn, idx, policy = rolled
             else:
-                cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, compact=recs)
+                cls_attn, idx, policy = ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None)
             if compact:
                 rows = ops.reserved_rows_map(idx, N)
                 x = ops.gather_rows(x, rows)
@@ -122,7 +117,7 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         hid = blk.mlp.fc1.out_features
         # full-row GEMMs (csrc/rowgemm.hip): the residual products also emit the LayerNorm that follows them
         rpt = ops.rowgemm_tile_rows(B * Nc, Nc)
-        fused = _ROW_FWD and ops.rowgemm_ok(D, D, rpt) and ops.rowgemm_ok(D, hid, rpt)
+        fused = ops.rowgemm_ok(D, D, rpt) and ops.rowgemm_ok(D, hid, rpt)
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         pre = None
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
@@ -134,18 +129,16 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
             def side(qkv=qkv, rowmax=rowmax, zinv=zinv, i=i, hm_fused=hm_fused):
                 if not hm_fused:
                     ops.attn_headmean(qkv, rowmax, zinv, B, H, N, D, policy=policy, self_keep=True, out=hm[i])
-                if recs is not None:
-                    ops.rollout_compact_layer(hm[i], recs[i], N)   # the r-independent part of this layer's rollout step, off the critical path
-                elif side_thr:
+                if side_thr:
                     ops.rollout_threshold(hm[i], thr[i], N)        # the rollout's order statistic of this layer, off the critical path
-            # (PPF_ROLLOUT_BATCH = n: the side launches of n consecutive layers go out under one main-stream event record)
+            # (the side launches of _ROLL_BATCH consecutive layers go out under one main-stream event record)
             # ... except in front of the reservation: the chain needs the last layers' thresholds first, and the main stream waits for it
-            lane.submit(side, (qkv, rowmax, zinv, hm, thr) + ((recs,) if recs is not None else ()), defer=(i % _ROLL_BATCH != _ROLL_BATCH - 1) and i < reserve_layer - _ROLL_TAIL)
+            lane.submit(side, (qkv, rowmax, zinv, hm, thr), defer=(i % _ROLL_BATCH != _ROLL_BATCH - 1) and i < reserve_layer - _ROLL_TAIL)
             if roll_side and i == reserve_layer - 1:
                 # the rollout chain (176 us, one workgroup per sample) depends only on the head-mean maps and thresholds the lane has
                 # produced: it runs there, right behind the last map, under the rest of this block instead of in front of the next one
                 rolled = ops.rollout_outputs(B, N, reserve_k, 1, x.device)
-                lane.submit(lambda: ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, out=rolled, compact=recs),
+                lane.submit(lambda: ops.rollout(hm, reserve_layer, B, N, reserve_k, lead=1, thr=thr if side_thr else None, out=rolled),
                             (hm, thr) + rolled)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         if fused:
@@ -154,20 +147,6 @@ def deit_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save, compact
         else:
             x1 = ops.gemm(ao, store.w16(blk.attn.proj.weight), epi=EPI_RESID, bias=blk.attn.proj.bias, res=x, rowscale=s1, rows_per_group=Nc)
             n2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, LN_EPS)
-        mlp_rows = (Nc + 1) // 2                                               # half-sample tiles (<= 112 rows) for the one-launch MLP
-        if fused and ops.mlp_fwd_ok(D, hid, mlp_rows):
-            # opt-in (PPF_MLP_FUSED=1): fc1 -> GELU -> fc2 -> residual + DropPath -> next LayerNorm in ONE launch (csrc/mlpfwd.hip)
-            nxt = feats.blocks[i + 1] if (i + 1 < nblk and not (compact and i + 1 == reserve_layer)) else None
-            x2, nn1, nm1, nr1, g, h = ops.mlp_fwd(n2, store.w16(blk.mlp.fc1.weight), blk.mlp.fc1.bias, store.w16(blk.mlp.fc2.weight), blk.mlp.fc2.bias,
-                                                  x1, mlp_rows, rowscale=s2, rows_per_group=Nc, ln_w=nxt.norm1.weight if nxt is not None else None,
-                                                  ln_b=nxt.norm1.bias if nxt is not None else None, eps=LN_EPS)
-            pre = (nn1, nm1, nr1) if nxt is not None else None
-            if save:
-                layers.append(dict(x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ao=ao, rowmax=rowmax, zinv=zinv, x1=x1, n2=n2,
-                                   mean2=mean2, rstd2=rstd2, h=h, g=g, policy=policy, s1=s1, s2=s2, N=Nc, eps_n=eps_n,
-                                   rows=rows if (compact and i == reserve_layer) else None))
-            x = x2
-            continue
         h = torch.empty((M, hid), dtype=torch.uint8, device=x.device)            # gelu'(pre-activation), 8-bit codes (csrc/gemm_common.h)
         g = ops.gemm(n2, store.w16(blk.mlp.fc1.weight), epi=EPI_GELU, bias=blk.mlp.fc1.bias, aux_out=h)
         if fused:
@@ -264,17 +243,13 @@ class WgradLane:
 
     def __init__(self, device):
         self.enabled = os.environ.get("PPF_WGRAD_STREAM", "1") != "0"
-        nl = int(os.environ.get("PPF_LANES", "1"))
-        # PPF_LANE_PRIORITY: HIP stream priority of the side streams (torch clamps to the device's range; larger = lower priority)
-        prio = int(os.environ.get("PPF_LANE_PRIORITY", "0"))
-        self.streams = [torch.cuda.Stream(device=device, priority=prio) for _ in range(nl)] if self.enabled else []
+        # ONE side stream at the default priority (two or three streams, and a high- / low-priority one, measured within noise in rounds 2-4)
+        self.streams = [torch.cuda.Stream(device=device)] if self.enabled else []
         self.raws = [st.cuda_stream for st in self.streams]
         self.last_read = {}         # data_ptr of a tracked buffer -> ticket of the last side-stream launch that reads it
         self.tracked = set()
         self.held = []              # tensors the lane reads, kept alive (so their memory is not reused) until the next join()
         self.pending = []           # deferred launches (fn, reads)
-        self._lane2_tags = set(filter(None, os.environ.get("PPF_LANE2_TAGS", "PROTO").replace("+", ",").split(",")))      # submits that go to the second side stream (PPF_LANES >= 2)
-        self._disabled_tags = {k[len("PPF_LANE_"):] for k, v in os.environ.items() if k.startswith("PPF_LANE_") and v == "0"}
 
     def track(self, t):
         """t is a buffer the main stream will write again during this backward pass (see before_overwrite)."""
@@ -282,7 +257,7 @@ class WgradLane:
         return t
 
     def submit(self, fn, reads, tag=None, defer=False):
-        if not self.enabled or (tag is not None and tag in self._disabled_tags):
+        if not self.enabled:
             fn()
             return
         self.pending.append((fn, reads, tag))
@@ -293,15 +268,10 @@ class WgradLane:
     def flush(self, tag=None):
         if not self.pending:
             return
-        # lane 0 carries the weight gradients; submits whose tag is in PPF_LANE2_TAGS (default: the long prototype-gradient kernels at the
-        # start of backward, "PROTO") go to the second side stream when there is one
-        waited = set()
+        raw = self.raws[0]
         try:
+            _lib.call("ppf_stream_wait_stream", raw, _lib.stream_ptr())      # ONE main-stream event record for everything pending
             for fn, reads, tg in self.pending:
-                raw = self.raws[1] if (tg in self._lane2_tags and len(self.raws) > 1) else self.raws[0]
-                if raw not in waited:
-                    _lib.call("ppf_stream_wait_stream", raw, _lib.stream_ptr())
-                    waited.add(raw)
                 _lib.push_stream(raw)
                 try:
                     fn()
@@ -347,10 +317,9 @@ def wgrad_lane(store):
 # 4-9 us of main-queue time (profiles/r4_queue_gaps.txt).  The first weight gradient of each branch (fc2, proj) is therefore parked and
 # launched together with the second one (fc1, qkv) under a single record: two records per block instead of four -- for the narrow
 # models (embed dim <= 256: deit_tiny +1.8 % same-box, cait_xxs24 +-0), whose kernels are short against the packet boundaries; at
-# D = 384 the later start of the parked GEMM costs more than the records (-0.5 %).  PPF_WGRAD_DEFER=0 / 1: never / always.
-_WGRAD_DEFER = os.environ.get("PPF_WGRAD_DEFER", "auto")
-_ROLL_TAIL = max(1, int(os.environ.get("PPF_ROLLOUT_TAIL", "1")))        # layers in front of the reservation whose side launches are never parked
-_ROLL_BATCH = max(1, int(os.environ.get("PPF_ROLLOUT_BATCH", "3")))      # 3: +0.9 % deit_tiny, +0.6 % deit_small same-box against 1
+# D = 384 the later start of the parked GEMM costs more than the records (-0.5 %).
+_ROLL_TAIL = 1        # layers in front of the reservation whose side launches are never parked
+_ROLL_BATCH = 3       # +0.9 % deit_tiny, +0.6 % deit_small same-box against 1
 
 
 def _wgrad(store, dy16, x16, weight, bias=None, defer=False):
@@ -359,25 +328,22 @@ def _wgrad(store, dy16, x16, weight, bias=None, defer=False):
     gw = store.grad_view(weight)
     gb = store.grad_view(bias) if bias is not None else None
     wgrad_lane(store).submit(lambda: ops.gemm(dy16, x16, trans_a=True, trans_b=True, epi=EPI_ATOMIC, out=gw.reshape(weight.shape[0], -1),
-                                              colsum=gb), (dy16, x16), defer=defer and (_WGRAD_DEFER == "1" or (_WGRAD_DEFER == "auto" and min(weight.shape[0], weight.shape[1]) <= 256)))
-
-
-_DGRAD_NT = os.environ.get("PPF_DGRAD_NT", "1") != "0"
+                                              colsum=gb), (dy16, x16), defer=defer and min(weight.shape[0], weight.shape[1]) <= 256)
 
 
 # Round 5: the input gradients of fc1 and qkv (N = 384 outputs, K = 1536 / 1152) through the PLAIN full-row GEMM (rowgemm_bf16: double-buffered
 # LDS-DMA stages, 57 / 46 us stand-alone) instead of the 224 x 128 tiles (single-buffered, ~100 us), the LayerNorm backward staying its own
 # launch: +1.0 % same-box at deit_small (fc1 +0.4, qkv +0.6, proj -0.2, all three +0.8; profiles/r5_dgrad_row.txt).  Bit mask fc1 (1) / qkv (2) / proj (4).
-_DGRAD_ROW = int(os.environ.get("PPF_DGRAD_ROW", "3"))
+_DGRAD_ROW = 3
 
 
 def _dgrad(dy16, store, weight, wt, rows=None, which=0):
     """dx = dy W as bf16.  With the transposed weight shadow (FlatStore.register_transposed) both operands are contraction-contiguous and
     the product can take the 224 x 128 direct-to-LDS kernel (csrc/gemm_bf16.hip gemm224g_kernel: one round of the chip instead of 1.54 for
-    the N = 384 outputs); otherwise the [K][N] weight is read transposed by the generic kernel.  PPF_DGRAD_NT=0: always the latter (A/B)."""
+    the N = 384 outputs); otherwise the [K][N] weight is read transposed by the generic kernel."""
     if wt is not None and (_DGRAD_ROW & which) and rows is not None and ops.rowgemm_ok(wt.shape[0], wt.shape[1], rows):
         return ops.rowgemm_bf16(dy16, wt, rows)
-    if wt is not None and _DGRAD_NT:
+    if wt is not None:
         return ops.gemm(dy16, wt, epi=EPI_BF16)
     return ops.gemm(dy16, store.w16(weight), trans_b=True, epi=EPI_BF16)
 
@@ -412,23 +378,19 @@ def deit_backward(ppnet, store, saved, df):
         _lib.run_live(lambda: gs.chunk_ready(gs.tail_chunk, also=lane.streams))
     # The bf16 branch gradient alternates between two buffers: the LayerNorm backward that produces the next one does not have to
     # wait for the side stream's weight-gradient GEMM that still reads the current one (the main stream would otherwise be tied to
-    # the progress of the side stream twice per block).  PPF_DYB_PINGPONG=0: one buffer, overwritten in place.  Round 4: four buffers in
+    # the progress of the side stream twice per block).  Round 4: four buffers in
     # rotation instead of two (the side stream lags up to a block behind at the start of backward: +0.6 % deit_small, +0.5 % deit_tiny
     # same-box; six = four).  Parking the prototype-gradient kernel until a few blocks' weight gradients have run was measured
     # 1 % SLOWER: at the start of backward it overlaps the serial head section, later it lands in the saturated part.
-    pingpong = os.environ.get("PPF_DYB_PINGPONG", "1") != "0"
     dyb_alt = None
 
     # buffers the branch gradient rotates through (2 = ping-pong; 4: +0.6 % same-box at D = 384).  The narrow models never reuse one
     # (64 > two per block): their side stream lags whole blocks behind and every reuse is a main-stream wait (cait_xxs24 +4 % same-box,
     # deit_tiny +0.2 %; 24-48 buffers of B*N*D bf16 = 0.2-0.5 GB of the 288); at D = 384 no reuse measured -0.7 % (larger footprint).
-    nring = int(os.environ.get("PPF_DYB_RING", "4" if D > 256 else "64"))
+    nring = 4 if D > 256 else 64
     ring = {}
 
     def next_dyb(cur, alt):
-        if not pingpong:
-            lane.before_overwrite(cur)
-            return cur, None
         if nring >= 64:                                   # never reused: nothing to order against the side stream, no marks
             return torch.empty_like(cur), cur
         bufs = ring.setdefault(tuple(cur.shape), [cur])
@@ -457,7 +419,7 @@ def deit_backward(ppnet, store, saved, df):
                  and ops.rowgemm_ok(D, D, rpt))
         # MLP branch: x2 = x1 + s2 * (gelu(n2 W1^T + b1) W2^T + b2)
         _wgrad(store, dyb, L["g"], blk.mlp.fc2.weight, None if bias_done else blk.mlp.fc2.bias, defer=True)
-        w2t = store.w16t(blk.mlp.fc2.weight) if _DGRAD_NT else None
+        w2t = store.w16t(blk.mlp.fc2.weight)
         if w2t is not None:      # contraction-contiguous operands: the direct-to-LDS kernel (gemm128g, four workgroups per CU) takes K = 384
             dh = ops.gemm(dyb, w2t, epi=EPI_DGELU, aux_in=L["h"])
         else:
@@ -537,8 +499,7 @@ class TokensFn(torch.autograd.Function):
             # W^T shadow of the input-gradient products: first needed in backward, so for the narrow models the transposition runs on the
             # side stream under the first blocks of the forward pass (launched with the lane's first flush; every path joins the lane before
             # backward): deit_tiny +0.8 % same-box; at D = 384 it is 47 us of a saturated chip wherever it runs (16 625 vs 16 597).
-            t16_side = os.environ.get("PPF_T16_SIDE", "auto")
-            if store._t16 is not None and not store._t16["fresh"] and (t16_side == "1" or (t16_side == "auto" and feats.embed_dim <= 256)):
+            if store._t16 is not None and not store._t16["fresh"] and feats.embed_dim <= 256:
                 wgrad_lane(store).submit(store.refresh_t16, (store.bf16, store._t16["buf"]), defer=True)
             else:
                 store.refresh_t16()

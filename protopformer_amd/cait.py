@@ -115,7 +115,7 @@ def _th_attention_fwd(blk, qkv, B, H, N, D, hm_slot):
         # one launch up to and including A.V, nothing of size N x N in fp32: only the softmax statistics (and the bf16 A the dV product reads)
         # are kept for backward
         a16, rowmax, zinv, ao = ops.th_fwd(qkv, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, blk.attn.proj_w.bias, hm_slot, B, H, N, D,
-                                           with_out=os.environ.get("PPF_TH_PV", "1") != "0")
+                                           with_out=ops.th_pv_fused())
         sp = (rowmax, zinv)
         if ao is not None:
             return ao, sp, a16
@@ -140,26 +140,23 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
     depth = len(feats.blocks)
     hm = torch.empty((depth, B, N, NP), dtype=torch.float32, device=x.device)
     thr = torch.empty((depth, B), dtype=torch.int32, device=x.device)          # rollout discard thresholds per (layer, sample)
-    # PPF_ROLLOUT_COMPACT=1: column-compressed records of the processed maps instead (opt-in, see backbone.forward_blocks)
-    rec_bytes = ops.rollout_compact_bytes(N) if os.environ.get("PPF_ROLLOUT_COMPACT", "0") != "0" else 0
-    recs = torch.empty((depth, B, rec_bytes), dtype=torch.uint8, device=x.device) if rec_bytes else None
     lane = wgrad_lane(store)
     layers = []
     x = x.reshape(M, D)
     # The projection / fc2 GEMM, the LayerScale residual and the LayerNorm that follows run as one full-row kernel (csrc/rowgemm.hip) where
     # the shape is covered: `pre` carries the next block's norm1 output out of the previous block's fc2 launch.
     rpt = ops.rowgemm_tile_rows(M, N)
-    rowk = (os.environ.get("PPF_CAIT_ROWGEMM", "1") != "0" and bool(feats.blocks) and ops.rowgemm_ok(D, D, rpt)
+    rowk = (bool(feats.blocks) and ops.rowgemm_ok(D, D, rpt)
             and ops.rowgemm_ok(D, feats.blocks[0].mlp.fc1.out_features, rpt))
     pre = None
-    rb = max(1, int(os.environ.get("PPF_ROLLOUT_BATCH", "3")))
+    rb = 3                                                                     # backbone._ROLL_BATCH
     for i, blk in enumerate(feats.blocks):
         n1, mean1, rstd1 = pre if pre is not None else ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         qkv = ops.gemm(n1, store.w16(blk.attn.qkv.weight), epi=EPI_BF16, bias=blk.attn.qkv.bias)
         ao, prob, a16 = _th_attention_fwd(blk, qkv, B, H, N, D, hm[i])
         # the rollout's order statistic, off the critical path (three layers per main-stream event record, as backbone.forward_blocks)
-        side = (lambda i=i: ops.rollout_compact_layer(hm[i], recs[i], N)) if recs is not None else (lambda i=i: ops.rollout_threshold(hm[i], thr[i], N))
-        lane.submit(side, (hm, thr) + ((recs,) if recs is not None else ()), defer=(i % rb != rb - 1) and i != len(feats.blocks) - 1)
+        side = lambda i=i: ops.rollout_threshold(hm[i], thr[i], N)
+        lane.submit(side, (hm, thr), defer=(i % rb != rb - 1) and i != len(feats.blocks) - 1)
         s1, s2 = _dp(dp, 2 * i), _dp(dp, 2 * i + 1)
         raw1 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if save else None
         if rowk:
@@ -198,7 +195,7 @@ def cait_blocks_fwd(feats, store, x, reserve_layer, reserve_k, dp, save):
         if j == reserve_layer:
             init_rows = rowmeans[:j]                                              # class-attention rows produced so far (cait:249-251)
             lane.join()
-            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows, thr=thr, compact=recs)
+            cls_attn, idx, policy = ops.rollout(hm, depth, B, N, reserve_k, lead=0, init_rows=init_rows, thr=thr)
         u = ops.cat_rows(cls, xt).reshape(B * N1, D)
         n, mean1, rstd1 = ops.layernorm_fwd(u, blk.norm1.weight, blk.norm1.bias, LN_EPS)
         kk = ops.gemm(n, store.w16(blk.attn.k.weight), epi=EPI_BF16, bias=blk.attn.k.bias)
@@ -257,7 +254,7 @@ def _th_attention_bwd(store, blk, L, dao, B, H, N, D):
         ds16, partial = ops.th_bwd(qkv, dao, blk.attn.proj_l.weight, blk.attn.proj_l.bias, blk.attn.proj_w.weight, rowmax, zinv, B, H, N, D)
         wgrad_lane(store).submit(lambda: ops.th_param_reduce(partial, B, H, N, gv(blk.attn.proj_w.weight), gv(blk.attn.proj_w.bias), gv(blk.attn.proj_l.bias),
                                                              gv(blk.attn.proj_l.weight)), (partial,),
-                                 defer=os.environ.get("PPF_TH_REDUCE_DEFER", "1") != "0")    # launched with the qkv weight gradient: one event record
+                                 defer=True)    # launched with the qkv weight gradient: one event record
     else:
         NP = prob.shape[-1]
         # dA_h[q][key] = sum_d dO_h[q][d] V_h[key][d]
@@ -357,13 +354,13 @@ def cait_backward(ppnet, store, saved, df):
     # 8 300 img/s with whole samples -- the opposite of deit_tiny, whose side stream carries relatively more weight-gradient work).
     rptb = ops.rowgemm_tile_rows(M, N)
     hid = feats.blocks[0].mlp.fc1.out_features if len(feats.blocks) else 0
-    rowb = (os.environ.get("PPF_CAIT_ROW_BWD", "1") != "0" and len(sa) > 0 and store.w16t(feats.blocks[0].mlp.fc1.weight) is not None
+    rowb = (len(sa) > 0 and store.w16t(feats.blocks[0].mlp.fc1.weight) is not None
             and ops.rowgemm_ok(D, hid, rptb) and ops.rowgemm_ok(D, 3 * D, rptb) and ops.rowgemm_ok(D, D, rptb))
     bias_done = True                       # the producer of the current dyb has already accumulated the bias gradient of the Linear above it
     # The bf16 branch gradient alternates between two buffers (as backbone.deit_backward): the kernel that produces the next one does not
     # wait for the side stream's weight-gradient GEMM that still reads the current one (measured: a 44 us stall per block otherwise).
     dyb_alt = None
-    nring = int(os.environ.get("PPF_DYB_RING", "4" if D > 256 else "64"))       # buffers in rotation, as backbone.deit_backward (narrow: no reuse)
+    nring = 4 if D > 256 else 64       # buffers in rotation, as backbone.deit_backward (narrow: no reuse)
     ring = []
 
     def next_dyb(cur, alt):

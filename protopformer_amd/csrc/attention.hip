@@ -1060,14 +1060,14 @@ int ppf_attn_fwd_hm(const void* qkv, void* out, const float* policy, float* rowm
         if (e != hipSuccess) { ppf_set_error("hipFuncSetAttribute(attn_fwd16): %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    static const bool packed = !(getenv("PPF_ATTN_FWD_PACKED") && atoi(getenv("PPF_ATTN_FWD_PACKED")) == 0);     // 0: the per-element softmax everywhere (A/B)
+    // round 6 (profiles/r6_attn_fwd_packed.txt): the packed softmax where only the last key tile is padded -- 65.8 -> 58.1 us stand-alone, +0.6 % of the step
     if (N <= 96) {
         if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, true, false>), grid, dim3(F16_NTHR), lds6, stream, p);
-        else if (packed && N > 80) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false, true>), grid, dim3(F16_NTHR), lds6, stream, p);
+        else if (N > 80) hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false, true>), grid, dim3(F16_NTHR), lds6, stream, p);
         else hipLaunchKernelGGL((attn_fwd16_kernel<64, 6, false, false>), grid, dim3(F16_NTHR), lds6, stream, p);
     } else {
         if (policy) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, true, false>), grid, dim3(F16_NTHR), lds13, stream, p);
-        else if (packed && N > 192) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false, true>), grid, dim3(F16_NTHR), lds13, stream, p);
+        else if (N > 192) hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false, true>), grid, dim3(F16_NTHR), lds13, stream, p);
         else hipLaunchKernelGGL((attn_fwd16_kernel<64, 13, false, false>), grid, dim3(F16_NTHR), lds13, stream, p);
     }
     PPF_LAUNCH_CHECK();
@@ -1101,14 +1101,13 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
     if (rc) return rc;
     PPF_CHECK_ARG(out && dout && dqkv && delta, PPF_ERR_ARG, "ppf_attn_bwd: null pointer");
     p.out = (bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.delta = delta;
-    static const int mode = getenv("PPF_ATTN_BWD_STREAM") ? atoi(getenv("PPF_ATTN_BWD_STREAM")) : 1;      // 0: the non-persistent one-pass kernel (A/B)
     // five products of 2 N^2 hd flops per (sample, head): S, dV, dP, dQ, dK; qkv + out + dout in, dqkv out
     PpfProbeScope probe(PPF_PROBE_ATTN_BWD, stream, 10.0 * B * H * (double)N * N * (D / H), 16.0 * B * N * (double)D + 8.0 * B * H * N);
     return dispatch(D / H, N, "ppf_attn_bwd", [&](auto hd, auto nt) {
         using G = Geo<decltype(nt)::value>;
         constexpr int HDv = decltype(hd)::value, NTv = decltype(nt)::value;
         if constexpr (HDv == 64) {
-            if (mode) {         // the streaming form of the one-pass kernel (default)
+            {                   // head_dim 64: the streaming form of the one-pass kernel (round 4: 163 -> 134 us, profiles/r4_attn_bwd.txt)
                 constexpr int lds_bytes = StreamLds<HDv, NTv>::BYTES;
                 auto kern = attn_bwd_stream_kernel<HDv, NTv>;
                 static bool attr_set = false;
@@ -1132,8 +1131,7 @@ int ppf_attn_bwd(const void* qkv, const void* out, const void* dout, void* dqkv,
                 PPF_LAUNCH_CHECK();
                 return 0;
             }
-        }
-        {                       // other head widths: the non-persistent one-pass kernel
+        } else {                // other head widths: the non-persistent one-pass kernel
             constexpr int lds_bytes = OnePassLds<HDv, NTv>::BYTES;
             auto kern = attn_bwd_onepass_kernel<HDv, NTv>;
             static bool attr_set = false;                  // one flag per instantiation (the lambda is instantiated per (hd, nt))

@@ -671,11 +671,11 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm224g_kernel(const GemmParams 
 // workgroup (the D = 192 models) the larger tile's prologue / epilogue outweigh the saved round -- fc1 + GELU and the x gelu' input
 // gradient of deit_tiny / cait_xxs24 (N = 768, K = 192; 1 182 vs 678 tiles) were measured 1.1 % SLOWER per step with this kernel.
 bool g4_eligible(const GemmParams& p);
+int g_force_g224 = 0;              // test hook (ppf_gemm_test_force_g224): 1 = every legal shape takes the 224-row kernel
 bool g224_eligible(const GemmParams& p, int epi) {
-    static const int mode = getenv("PPF_GEMM_G224") ? atoi(getenv("PPF_GEMM_G224")) : 1;
-    if (!mode || epi != EPI_BF16 || p.bias != nullptr || p.kpad || p.K % BK != 0 || p.N % 8 != 0 || (p.ldc & 7) != 0) return false;
+    if (epi != EPI_BF16 || p.bias != nullptr || p.kpad || p.K % BK != 0 || p.N % 8 != 0 || (p.ldc & 7) != 0) return false;
     if ((long long)p.M * p.lda >= (1ll << 30) || (long long)p.N * p.ldb >= (1ll << 30)) return false;
-    if (mode == 2) return true;
+    if (g_force_g224) return true;
     if (p.K < 768) return false;                 // round 5: the K = 384 input gradient of proj is +0.8 % of the deit_small step on 128 x 128 tiles (six K tiles do not pay for the larger tile's prologue / epilogue)
     static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long long tn = (p.N + BN - 1) / BN;
@@ -710,11 +710,9 @@ template <int EPI>
 int launch_g4(const GemmParams& p, hipStream_t stream) { return launch_g4_mt<EPI, 2, 4>(p, stream); }
 
 bool g4_eligible(const GemmParams& p) {
-    static const int mode = getenv("PPF_GEMM_G4") ? atoi(getenv("PPF_GEMM_G4")) : 1;
     // measured (profiles/r1_gemm_ab.txt): -12 % at K = 384 with N >= 1152 (qkv 74 -> 65 us, fc1+GELU 151 -> 133), neutral at N = 384,
     // +5 % at K = 1536 where the register-prefetched kernel overlaps better inside a workgroup -> short contractions only
-    if (mode == 2) return p.K % BK == 0 && !p.kpad;
-    return mode && p.K % BK == 0 && p.K <= 512 && p.N >= 512 && !p.kpad && (long long)p.M * p.lda < (1ll << 30) &&
+    return p.K % BK == 0 && p.K <= 512 && p.N >= 512 && !p.kpad && (long long)p.M * p.lda < (1ll << 30) &&
            (long long)p.N * p.ldb < (1ll << 30) && (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) >= 512;
 }
 
@@ -739,17 +737,10 @@ int launch_impl(const GemmParams& p, int splitk, hipStream_t stream, int nbatch)
 }
 
 // Tile choice: 256x128 when the m extent is tall enough to fill the chip with 256-row tiles (activation GEMMs), else 128x128.
-// PPF_GEMM_MT=2 / 4 forces one (A/B measurements in profiles/).
+// (The 256x128 form of this kernel was 5-30 % slower at every shape of these models -- profiles/r1_gemm_tile_ab.txt, r4_wgrad_tiles.txt -- and
+// is no longer instantiated.)
 template <bool TA, bool TB, int EPI, bool COLSUM>
 int launch(const GemmParams& p, int splitk, hipStream_t stream, int nbatch = 1) {
-    static const int forced = getenv("PPF_GEMM_MT") ? atoi(getenv("PPF_GEMM_MT")) : 0;
-    const long long tall_tiles = (long long)((p.M + 255) / 256) * ((p.N + BN - 1) / BN) * splitk * nbatch;
-    // measured (profiles/r1_gemm_tile_ab.txt): the 256x128 tile is 5-30 % slower at every shape of this model -> opt-in only
-    (void)tall_tiles;
-    // (round 4: the 256x128 form was also tried for the weight gradient with 1536 output rows, same and doubled K slices: 12.2k / 13.4k
-    // img/s against 15.6k -- profiles/r4_wgrad_tiles.txt)
-    const bool tall = forced == 4;
-    if (tall) return launch_impl<TA, TB, EPI, COLSUM, 4>(p, splitk, stream, nbatch);
     return launch_impl<TA, TB, EPI, COLSUM, 2>(p, splitk, stream, nbatch);
 }
 
@@ -806,7 +797,7 @@ struct Probe {
         if (used == pool.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             // timing events that the host only reads after a device synchronise: no system-scope fence at each record
-            const unsigned fl = (getenv("PPF_PROBE_SYSFENCE") && atoi(getenv("PPF_PROBE_SYSFENCE")) != 0) ? 0u : hipEventDisableSystemFence;
+            const unsigned fl = hipEventDisableSystemFence;
             (void)hipEventCreateWithFlags(&a, fl); (void)hipEventCreateWithFlags(&b, fl);
             pool.emplace_back(a, b);
         }
@@ -827,8 +818,7 @@ int pick_splitk(int M, int N, int K) {
     // the side stream under the dgrad chain, where a smaller footprint wins (step time: 432 <= 540 < 768), so that is the default.
     // Narrow layers (an output side <= 256: the D = 192 models) take half as many: their reduce kernel reads every slab back and is a
     // third of the side stream's time there (216: deit_tiny +1.5 %, cait_xxs24 +2.9 % same-box; 144: -2 %; at D = 384 288: -4 %).
-    static const int target_env = getenv("PPF_SPLITK_TARGET") ? atoi(getenv("PPF_SPLITK_TARGET")) : 0;
-    const int target = target_env > 0 ? target_env : (min(M, N) <= 256 ? 216 : 432);
+    const int target = min(M, N) <= 256 ? 216 : 432;
     int s = target / tiles;
     const int maxs = (K + 4 * BK - 1) / (4 * BK);      // at least 4 K-tiles per slice
     if (s > maxs) s = maxs;
@@ -841,6 +831,10 @@ int pick_splitk(int M, int N, int K) {
 }  // namespace
 
 extern "C" {
+
+// Test hook: force = 1 routes every shape the 224 x 128 kernel can legally take to it (tests/test_gpu_gemm.py covers its ragged edges at
+// shapes the cost model would give to other kernels); 0 restores the cost model.  Not thread-safe; never set on the product path.
+int ppf_gemm_test_force_g224(int force) { g_force_g224 = force != 0; return 0; }
 
 // Bytes of split-K workspace ppf_gemm_bf16 needs for an accumulating (epi = 6) problem of this shape.
 size_t ppf_gemm_workspace_bytes(int M, int N, int K) {
@@ -875,7 +869,6 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
     if (epi == EPI_GELU) PPF_CHECK_ARG(aux_out != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=2 needs aux_out");
     if (epi == EPI_DGELU) PPF_CHECK_ARG(aux_in != nullptr, PPF_ERR_ARG, "ppf_gemm_bf16: epi=5 needs aux_in");
     if (!trans_a && !trans_b) {
-        if (nt256_eligible(p, epi)) return launch_nt256(p, epi, stream);
         if (g224_eligible(p, epi)) return launch_g224(p, stream);
         if (g4_eligible(p)) {
             switch (epi) {
@@ -920,12 +913,11 @@ int ppf_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
                 // eight-wave tiles where one output side is long and the other at least 384: 256 x 128 (rows) or 128 x 256 (columns).
                 // Same-box: deit_small +0.1 .. +0.4 % in four A/Bs with 19.5 % fewer L2 requests from the weight gradients
                 // (profiles/r4_wgrad_l2_knockout.txt); the D = 192 models lose (deit_tiny -2.8 %, cait_xxs24 -0.8 %: a third of their
-                // 128-column tiles is padding).  PPF_WGRAD8=0: 128 x 128 always.
-                static const int w8 = getenv("PPF_WGRAD8") ? atoi(getenv("PPF_WGRAD8")) : 1;
+                // 128-column tiles is padding).
                 const bool wide = (M < N ? M : N) >= 320;
                 int rc;
-                if (w8 && wide && M >= 512 && M >= N && (M % 256 == 0 || M >= 1024)) rc = launch_wgrad8<4, 2>(p, ns, stream);
-                else if (w8 && wide && N >= 512 && (N % 256 == 0 || N >= 1024)) rc = launch_wgrad8<2, 4>(p, ns, stream);
+                if (wide && M >= 512 && M >= N && (M % 256 == 0 || M >= 1024)) rc = launch_wgrad8<4, 2>(p, ns, stream);
+                else if (wide && N >= 512 && (N % 256 == 0 || N >= 1024)) rc = launch_wgrad8<2, 4>(p, ns, stream);
                 else rc = launch<true, true, EPI_PARTIAL, true>(p, ns, stream);
                 if (rc) return rc;
                 if (g_probe.on) {

@@ -1,4 +1,4 @@
-// Shared declarations of the bf16 MFMA GEMM family (gemm_bf16.hip: 128x128 generic kernel; gemm_nt256.hip: 256x256 pipelined kernel).
+// Shared declarations of the bf16 MFMA GEMM family (gemm_bf16.hip; the retired 256x256 kernel under scripts/gpu/experiments/gemm_nt256 includes it too).
 #pragma once
 #include "ppf_common.h"
 
@@ -117,11 +117,7 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n0, fl
         gelu_erf_both2(ppf_float2{v[2], v[3]}, g23, d23);
         const float g[4] = {g01.x, g01.y, g23.x, g23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
         // gelu' is not read again before the backward pass: streaming (non-temporal) store, keeps L2 / MALL for the operands
-#ifdef PPF_GELU8_PLAIN_STORE
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p.aux_out) + (size_t)m * p.ldaux + n0) = gelu8_pack4(d[0], d[1], d[2], d[3]);
-#else
         __builtin_nontemporal_store(gelu8_pack4(d[0], d[1], d[2], d[3]), reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p.aux_out) + (size_t)m * p.ldaux + n0));
-#endif
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n0) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
     } else if constexpr (EPI == EPI_SIGMOID_F32) {
 #pragma unroll
@@ -184,11 +180,7 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, int m, int n0, c
         // gelu' is not read again before the backward pass: streaming (non-temporal) store, keeps L2 / MALL for the operands
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 dv = {gelu8_pack4(d[0].x, d[0].y, d[1].x, d[1].y), gelu8_pack4(d[2].x, d[2].y, d[3].x, d[3].y)};
-#ifdef PPF_GELU8_PLAIN_STORE
-        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.aux_out) + (size_t)m * p.ldaux + n0) = dv;
-#else
         __builtin_nontemporal_store(dv, reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.aux_out) + (size_t)m * p.ldaux + n0));
-#endif
         *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(g[0].x, g[0].y), pack_bf16x2(g[1].x, g[1].y), pack_bf16x2(g[2].x, g[2].y), pack_bf16x2(g[3].x, g[3].y));
     } else if constexpr (EPI == EPI_DGELU) {
         float ha[4], hb[4];
@@ -199,8 +191,5 @@ __device__ __forceinline__ void epi_store8(const GemmParams& p, int m, int n0, c
     }
 }
 
-// 256x256x64 pipelined kernel for contraction-contiguous operands (gemm_nt256.hip)
-bool nt256_eligible(const GemmParams& p, int epi);
-int launch_nt256(const GemmParams& p, int epi, hipStream_t stream);
 
 }  // namespace ppfg

@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 struct LnBwdParams {
-    int nt = 0;           // PPF_LN_NT bit mask (measurement): 1 x, 2 dx_out, 4 cast_out, 8 dy, 16 dres_in accessed non-temporally
     const bf16_t* dy; const float* x; const int* row_map; const float* w; const float* mean; const float* rstd;
     const float* dres_in; float* dx_out; float* dw; float* db;
     bf16_t* cast_out; const float* rowscale; int rows_per_group; const float* colscale; float* dbias_next;
@@ -162,15 +161,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
     if (p.cast_out) { flush(anb, p.dbias_next, 2); if (p.branch) flush(acs, p.dcolscale, 3); }
 }
 
-typedef float lnf4 __attribute__((ext_vector_type(4)));
-typedef uint32_t lnu2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ lnf4 ld_f4(const float* q, bool nt) { const lnf4* a = reinterpret_cast<const lnf4*>(q); return nt ? __builtin_nontemporal_load(a) : *a; }
-__device__ __forceinline__ lnu2 ld_u2(const bf16_t* q, bool nt) { const lnu2* a = reinterpret_cast<const lnu2*>(q); return nt ? __builtin_nontemporal_load(a) : *a; }
-__device__ __forceinline__ void st_f4(float* q, lnf4 v, bool nt) { lnf4* a = reinterpret_cast<lnf4*>(q); if (nt) __builtin_nontemporal_store(v, a); else *a = v; }
-__device__ __forceinline__ void st_u2(bf16_t* q, lnu2 v, bool nt) { lnu2* a = reinterpret_cast<lnu2*>(q); if (nt) __builtin_nontemporal_store(v, a); else *a = v; }
-
 // Bandwidth-oriented variant for D = 32*V*NJ (V = 4: D % 128 == 0, V = 2: D % 64 == 0): half a wavefront per row, so a
 // wave streams two independent rows at a time with 16-/8-byte accesses (twice the loads in flight of the generic kernel).
+// (round 6: non-temporal loads / stores of any of the five streams change nothing, stand-alone or in the step: profiles/r6_ln_bwd_nt.txt)
 // LS = false: no LayerScale operands (colscale / branch / dcolscale all null, the DeiT case): 24 fewer live registers -> 4 waves/SIMD.
 template <int V, int NJ, bool LS>
 __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
@@ -197,7 +190,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
         for (int j = 0; j < NJ; ++j) {
             const int c = V * l32 + 32 * V * j;
             if (p.dres_in && ok) {
-                if constexpr (V == 4) { const lnf4 t = ld_f4(p.dres_in + src * D + c, p.nt & 16); dx[j][0] = t.x; dx[j][1] = t.y; dx[j][2] = t.z; dx[j][3] = t.w; }
+                if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p.dres_in + src * D + c); dx[j][0] = t.x; dx[j][1] = t.y; dx[j][2] = t.z; dx[j][3] = t.w; }
                 else { const float2 t = *reinterpret_cast<const float2*>(p.dres_in + src * D + c); dx[j][0] = t.x; dx[j][1] = t.y; }
             } else {
 #pragma unroll
@@ -214,8 +207,8 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
                 float xv[V], dyv[V];
                 if (ok) {
                     if constexpr (V == 4) {
-                        const lnf4 t = ld_f4(p.x + src * D + c, p.nt & 1); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-                        const lnu2 u = ld_u2(p.dy + (size_t)r * D + c, p.nt & 8);
+                        const float4 t = *reinterpret_cast<const float4*>(p.x + src * D + c); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                        const uint2 u = *reinterpret_cast<const uint2*>(p.dy + (size_t)r * D + c);
                         const float2 a = unpack_bf16x2(u.x), b = unpack_bf16x2(u.y); dyv[0] = a.x; dyv[1] = a.y; dyv[2] = b.x; dyv[3] = b.y;
                     } else {
                         const float2 t = *reinterpret_cast<const float2*>(p.x + src * D + c); xv[0] = t.x; xv[1] = t.y;
@@ -249,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
         for (int j = 0; j < NJ; ++j) {
             const int c = V * l32 + 32 * V * j;
             if (p.dx_out) {
-                if constexpr (V == 4) st_f4(p.dx_out + src * D + c, lnf4{dx[j][0], dx[j][1], dx[j][2], dx[j][3]}, p.nt & 2);
+                if constexpr (V == 4) *reinterpret_cast<float4*>(p.dx_out + src * D + c) = make_float4(dx[j][0], dx[j][1], dx[j][2], dx[j][3]);
                 else *reinterpret_cast<float2*>(p.dx_out + src * D + c) = make_float2(dx[j][0], dx[j][1]);
             }
             if (p.cast_out) {
@@ -274,7 +267,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwdParams p) {
                     const float2 rt = unpack_bf16x2(pk[e / 2]);
                     anb[j][e] += rt.x; anb[j][e + 1] += rt.y;
                 }
-                if constexpr (V == 4) st_u2(p.cast_out + src * D + c, lnu2{pk[0], pk[1]}, p.nt & 4);
+                if constexpr (V == 4) *reinterpret_cast<uint2*>(p.cast_out + src * D + c) = make_uint2(pk[0], pk[1]);
                 else *reinterpret_cast<uint32_t*>(p.cast_out + src * D + c) = pk[0];
             }
         }
@@ -333,7 +326,7 @@ __global__ __launch_bounds__(1024) void ln_colsum_reduce_kernel(const float* __r
 int ln_bwd_grid(int rows) {
     // four 4-wave workgroups per CU is what the register budget holds: a grid of exactly that size has no partly filled last round
     // (stand-alone 79 -> 64 us at 50 432 rows) and writes a third fewer column partials
-    static const int cap = getenv("PPF_LN_BWD_GRID") ? atoi(getenv("PPF_LN_BWD_GRID")) : 1024;
+    constexpr int cap = 1024;
     const int g = (rows + WAVES * 8 - 1) / (WAVES * 8);
     return g < cap ? g : cap;
 }
@@ -380,8 +373,6 @@ int ppf_layernorm_bwd(const void* dy, const float* x, const int* row_map, const 
     p.dw = dw; p.db = db; p.cast_out = (bf16_t*)cast_out; p.rowscale = rowscale; p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.colscale = colscale; p.dbias_next = dbias_next; p.branch = (const bf16_t*)branch; p.dcolscale = dcolscale; p.rows = rows; p.D = D;
     const int grid = ln_bwd_grid(rows);                                    // >= 8 rows per wave: amortise the column flush
-    static const int nt_mask = getenv("PPF_LN_NT") ? atoi(getenv("PPF_LN_NT")) : 0;
-    p.nt = nt_mask;
     PPF_CHECK_ARG(partial == nullptr || partial_bytes >= (size_t)(grid + LN_RS) * 4 * D * sizeof(float), PPF_ERR_ARG,
                   "ppf_layernorm_bwd: partial-sum workspace needs ppf_layernorm_bwd_blocks(rows)*4*D*4 = %zu bytes", (size_t)(grid + LN_RS) * 4 * D * sizeof(float));
     p.partial = partial;

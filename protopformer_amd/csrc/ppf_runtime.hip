@@ -48,9 +48,8 @@ hipEvent_t ring_event(int64_t seq) {
     const int i = (int)(seq % RING);
     if (!g_ring_made[i]) {
         // ordering between two streams of ONE device: no timestamps and no system-scope fence (the host never inspects these events,
-        // agent scope is what a kernel boundary gives anyway).  PPF_EVENT_SYSFENCE=1 restores the default system-scope release.
-        static const bool sysfence = getenv("PPF_EVENT_SYSFENCE") && atoi(getenv("PPF_EVENT_SYSFENCE")) != 0;
-        (void)hipEventCreateWithFlags(&g_ring[i], hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence));
+        // agent scope is what a kernel boundary gives anyway)
+        (void)hipEventCreateWithFlags(&g_ring[i], hipEventDisableTiming | hipEventDisableSystemFence);
         g_ring_made[i] = true;
     }
     return g_ring[i];

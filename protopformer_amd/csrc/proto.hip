@@ -19,9 +19,7 @@
 
 namespace {
 
-#ifndef PPF_PROTO_OCC
-#define PPF_PROTO_OCC 3
-#endif
+constexpr int PROTO_OCC = 3;     // workgroups per CU of the forward kernels at <= 3 token tiles
 constexpr int PB = 128;           // prototypes per workgroup (4 waves x 32)
 constexpr int BKF = 32;           // contraction chunk (floats)
 constexpr int LDP = BKF + 1;      // padded LDS pitch: conflict-free ds_read_b32 for the MFMA operands
@@ -311,7 +309,7 @@ __global__ __launch_bounds__(256, TT <= 3 ? 3 : 2) void proto_fwd6_kernel(const 
 }
 
 template <int TT, bool POOL>
-__global__ __launch_bounds__(256, TT <= 3 ? PPF_PROTO_OCC : 2) void proto_fwd_kernel(const ProtoFwdParams p) {
+__global__ __launch_bounds__(256, TT <= 3 ? PROTO_OCC : 2) void proto_fwd_kernel(const ProtoFwdParams p) {
     constexpr int ROWS = TT * 32;
     constexpr int STAGE = (ROWS + PB) * LDP;                       // floats
     constexpr int XPOSE = 4 * 16 * (ROWS + 1);                     // per-wave [16 p][ROWS+1] transpose tiles (two halves per map): with
@@ -971,16 +969,14 @@ __global__ __launch_bounds__(256) void proto_single_fixup_kernel(float* __restri
 struct ProtoTiled { bool ok; int slots, pt, sg, spg, R, nchunks, chunk_pad; size_t ws_bytes; };
 ProtoTiled proto_tiled_geometry(int B, int T, int P, int Dp, int64_t stride_b, int t0) {
     ProtoTiled g{};
-    static const int mode = getenv("PPF_PROTO_TILED") ? atoi(getenv("PPF_PROTO_TILED")) : 1;
-    static const int sg_env = getenv("PPF_PROTO_SG") ? atoi(getenv("PPF_PROTO_SG")) : 0;
-    if (!mode || T < 2 || Dp % 4 || Dp > 384 || stride_b % 4 || ((int64_t)t0 * Dp) % 4) return g;
+    if (T < 2 || Dp % 4 || Dp > 384 || stride_b % 4 || ((int64_t)t0 * Dp) % 4) return g;
     const int row_bytes = Dp * 4, rmax = min(128, (76 * 1024) / row_bytes);  // two images of <= 76 KiB, <= 128 rows each
     g.slots = 16;                                                            // 16 x 6 accumulator registers per lane at Dp = 384
     g.nchunks = (T + rmax - 1) / rmax;
     g.R = (T + g.nchunks - 1) / g.nchunks;
     g.chunk_pad = ((g.R * row_bytes + 1023) / 1024) * 1024;
     g.pt = (P + PT_NW * g.slots - 1) / (PT_NW * g.slots);
-    int sg = sg_env > 0 ? sg_env : (256 + g.pt - 1) / g.pt;                  // about one workgroup per CU
+    int sg = (256 + g.pt - 1) / g.pt;                  // about one workgroup per CU
     if (sg > B) sg = B;
     g.spg = (B + sg - 1) / sg;
     g.sg = (B + g.spg - 1) / g.spg;
@@ -1015,11 +1011,9 @@ int ppf_proto_fwd(const float* tok, int64_t stride_b, int t0, int T, const float
     // algorithmic work: the (B T) x Dp . Dp x P contraction; tokens + prototypes in, the maps that are asked for + max / arg-max out
     PpfProbeScope probe(PPF_PROBE_PROTO_FWD, stream, 2.0 * B * T * (double)Dp * P,
                         4.0 * ((double)B * T * Dp + (double)P * Dp + (double)B * P * T * ((dist_full ? 1 : 0) + (act_full ? 1 : 0)) + 2.0 * B * P));
-    // default: the split-bf16 contraction; PPF_PROTO_FP32=1 (or Dp not a multiple of 16): the fp32-MFMA kernel
-    static const int fp32_mfma = getenv("PPF_PROTO_FP32") ? atoi(getenv("PPF_PROTO_FP32")) : 0;
-    static const int presplit = getenv("PPF_PROTO_PRESPLIT") ? atoi(getenv("PPF_PROTO_PRESPLIT")) : 1;
-    const bool x6 = !fp32_mfma && Dp % 16 == 0;
-    const bool pre = x6 && presplit && T > 1 && workspace && workspace_bytes >= ppf_proto_fwd_workspace(P, Dp) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    // the split-bf16 contraction (six exact products); Dp not a multiple of 16: the fp32-MFMA kernel
+    const bool x6 = Dp % 16 == 0;
+    const bool pre = x6 && T > 1 && workspace && workspace_bytes >= ppf_proto_fwd_workspace(P, Dp) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
     if (pre) {
         p.pre = reinterpret_cast<const uint4*>(workspace);
         float* p2 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)gx * PB * Dp * 6);
@@ -1077,8 +1071,7 @@ static int proto_bwd_launch(ProtoBwdParams p, void* workspace, size_t workspace_
         if (p.dtok) {
             if (p.g_full) hipLaunchKernelGGL(proto_bwd_mark_kernel, dim3(W, B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
             else hipLaunchKernelGGL(proto_bwd_mark_sparse_kernel, dim3(B), dim3(256), 0, stream, p, (uint32_t*)workspace, W);
-            static const int tok_nw = getenv("PPF_PROTO_TOK_NW") ? atoi(getenv("PPF_PROTO_TOK_NW")) : 1;
-            if (W <= 64 && tok_nw == 1) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 1>), dim3(B * T), dim3(64), 0, stream, p, (const uint32_t*)workspace, W);
+            if (W <= 64) hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 1>), dim3(B * T), dim3(64), 0, stream, p, (const uint32_t*)workspace, W);
             else hipLaunchKernelGGL((proto_bwd_tokens_kernel<NJ, 8>), dim3(B * T), dim3(512), 0, stream, p, (const uint32_t*)workspace, W);
         }
         if (p.dprotos && tg.ok) {

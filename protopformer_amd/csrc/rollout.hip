@@ -30,8 +30,6 @@ struct RolloutParams {
     float identity;
     int k;
     const uint32_t* thr;     // optional [L][B]: per (layer, sample) discard thresholds computed ahead by rollout_threshold_kernel
-    const unsigned char* compact;   // optional [L][B][rec_bytes]: the layers' processed matrices in column-compressed form
-    int rec_bytes, cap;             //   (rollout_compact_kernel); hm / thr are then not read
     float* cls_attn;         // [B][Nk]
     int* idx;                // [B][k] ascending
     float* policy;           // [B][1+Nk]
@@ -97,113 +95,7 @@ __device__ uint32_t radix_select(const float (&v)[NV], int target, uint32_t* his
     return prefix;
 }
 
-// ---- column-compressed form of one layer's processed matrix a_l = rownorm((discard(f_l) + identity I) / (1 + identity)) ----------------
-// 90 % of a layer's entries are discarded, and everything the chain does with the rest except the product with r itself -- the order
-// statistic, the row sums -- does not depend on r.  rollout_compact_kernel (side stream, right behind the layer's head-mean map) leaves
-// per (layer, sample) a record  [s: N row sums][diag: N][colptr: N+1 int][vals: cap fp32][rows: cap u8]  of the kept OFF-diagonal
-// entries column by column, rows ascending (a[row][col] = kept value / (1 + identity), NOT yet divided by the row sum), so that the
-// chain at the reservation layer -- on the critical path -- reads 22 KB per layer instead of the 157 KB map and does
-//     coef_i = r_i / s_i,   r'_j = sum_{entries of column j} coef_row * val  +  coef_j * diag_j.
-__host__ __device__ inline int rec_off_diag(int N) { return N * 4; }
-__host__ __device__ inline int rec_off_colptr(int N) { return 2 * N * 4; }
-__host__ __device__ inline int rec_off_vals(int N) { return (3 * N + 1) * 4; }
-__host__ __device__ inline int rec_off_rows(int N, int cap) { return (3 * N + 1) * 4 + cap * 4; }
-__host__ __device__ inline int rec_size(int N, int cap) { return ((3 * N + 1) * 4 + cap * 5 + 15) & ~15; }
-
-__global__ __launch_bounds__(NTHR) void rollout_compact_kernel(const float* __restrict__ f_layer, int N, int NP, int kdrop, float identity, int cap,
-                                                               int rec_bytes, unsigned char* __restrict__ recs) {
-    __shared__ uint32_t hist[HCOPIES * HSTRIDE];
-    __shared__ uint32_t misc[16];
-    __shared__ uint32_t bits[256 * 8];                 // [column][row word]: kept off-diagonal entries
-    __shared__ int colptr[257];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    const float* f = f_layer + (size_t)b * N * NP;
-    unsigned char* rec = recs + (size_t)b * rec_bytes;
-    float* rs = reinterpret_cast<float*>(rec);
-    float* rdiag = reinterpret_cast<float*>(rec + rec_off_diag(N));
-    int* rcolptr = reinterpret_cast<int*>(rec + rec_off_colptr(N));
-    float* rvals = reinterpret_cast<float*>(rec + rec_off_vals(N));
-    unsigned char* rrows = rec + rec_off_rows(N, cap);
-    const float inv_norm = 1.0f / (1.0f + identity);
-    float v[RPW * CPL];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = wave + NWAVE * i;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int col = lane + 64 * c;
-            v[i * CPL + c] = (row < N && col < N) ? f[(size_t)row * NP + col] : INFINITY;
-        }
-    }
-    const uint32_t thr = kdrop > 0 ? radix_select<RPW * CPL>(v, kdrop, hist, misc) : 0u;
-    for (int i = tid; i < 256 * 8; i += NTHR) bits[i] = 0;
-    __syncthreads();
-    // row sums and diagonal exactly as the dense chain forms them; kept off-diagonal entries into the column bitmaps
-    uint32_t keptmask[RPW];                            // bit c: entry (row_i, lane + 64 c) is a kept off-diagonal one
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = wave + NWAVE * i;
-        float s = 0.f;
-        keptmask[i] = 0;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int col = lane + 64 * c;
-            const bool ok = row < N && col < N;
-            const bool kept = ok && !(kdrop > 0 && order_key(v[i * CPL + c]) <= thr);
-            float x = kept ? v[i * CPL + c] : 0.f;
-            if (ok && col == row) x += identity;
-            const float a = x * inv_norm;
-            s += a;
-            v[i * CPL + c] = a;                        // from here on: the processed value
-            if (ok && col == row) rdiag[row] = a;
-            if (kept && col != row) { keptmask[i] |= 1u << c; atomicOr(&bits[col * 8 + (row >> 5)], 1u << (row & 31)); }
-        }
-        s = wave_sum(s);
-        if (row < N && lane == 0) rs[row] = s;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        int cnt = 0;
-        if (tid < N)
-#pragma unroll
-            for (int w = 0; w < 8; ++w) cnt += __popc(bits[tid * 8 + w]);
-        colptr[tid + 1] = cnt;
-    }
-    __syncthreads();
-    if (tid < 64) {                                    // exclusive scan of <= 256 column counts by one wave (4 per lane)
-        int c4[4], tot = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { c4[q] = colptr[1 + tid * 4 + q]; tot += c4[q]; }
-        int incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
-        int run = incl - tot;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { colptr[tid * 4 + q] = run; run += c4[q]; }
-        if (tid == 63) colptr[256] = run;
-    }
-    __syncthreads();
-    if (tid <= N) rcolptr[tid] = colptr[min(tid, 256)];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = wave + NWAVE * i;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            if ((keptmask[i] >> c) & 1u) {
-                const int col = lane + 64 * c;
-                int pos = colptr[col];
-                const int rw = row >> 5;
-                for (int w = 0; w < rw; ++w) pos += __popc(bits[col * 8 + w]);
-                pos += __popc(bits[col * 8 + rw] & ((1u << (row & 31)) - 1u));
-                if (pos < cap) { rvals[pos] = v[i * CPL + c]; rrows[pos] = (unsigned char)row; }
-            }
-        }
-    }
-}
-
-// ---- shared by the dense and the compact chain kernels (all threads of a >= 256-thread workgroup call them)
+// ---- shared by the phases of the chain kernel (all threads of a >= 256-thread workgroup call them)
 __device__ void rollout_init_vector(const RolloutParams& p, int b, float* r, float* vals, uint32_t* hist, uint32_t* misc) {
     const int tid = threadIdx.x, N = p.N;
     const float inv_norm = 1.0f / (1.0f + p.identity);
@@ -332,66 +224,6 @@ __global__ __launch_bounds__(NTHR) void rollout_kernel(const RolloutParams p) {
     rollout_emit(p, b, r, vals, sel);
 }
 
-// The chain over the column-compressed records of rollout_compact_kernel: per layer (last first) the record (22 KB at N = 197) is copied into
-// LDS while the previous one is used; coef_i = r_i / s_i; four lanes per column add their quarter of the column's entries (ascending) and the
-// four partial sums are combined in a fixed order.  Deterministic; same arithmetic as the dense chain up to the order of the column sums.
-__global__ __launch_bounds__(NTHR) void rollout_chain_compact_kernel(const RolloutParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];          // two record images
-    __shared__ uint32_t hist[HCOPIES * HSTRIDE];
-    __shared__ uint32_t misc[16];
-    __shared__ float r[256];
-    __shared__ float coef[256];
-    __shared__ float vals[256];
-    __shared__ int sel[256];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x, N = p.N;
-    const int rec16 = p.rec_bytes / 16;               // <= 2 * NTHR (host check): two 16-byte pieces per thread
-    uint4 pre[2];
-    auto gload = [&](int l) {                          // record (l, b) -> registers
-        const uint4* src = reinterpret_cast<const uint4*>(p.compact + ((size_t)l * p.B + b) * p.rec_bytes);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = tid + u * NTHR; pre[u] = i < rec16 ? src[i] : make_uint4(0u, 0u, 0u, 0u); }
-    };
-    auto sstore = [&](int buf) {                       // registers -> record image buf
-        uint4* dst = reinterpret_cast<uint4*>(rc_smem + (size_t)buf * p.rec_bytes);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = tid + u * NTHR; if (i < rec16) dst[i] = pre[u]; }
-    };
-    gload(p.L - 1);                                    // flies under the initial vector
-    rollout_init_vector(p, b, r, vals, hist, misc);
-    sstore(0);
-    int buf = 0;
-#pragma unroll 1
-    for (int l = p.L - 1; l >= 0; --l, buf ^= 1) {
-        __syncthreads();                               // image buf complete (and r of the previous layer written)
-        if (l > 0) gload(l - 1);                       // the next record travels while this one is used
-        const unsigned char* rec = rc_smem + (size_t)buf * p.rec_bytes;
-        const float* rs = reinterpret_cast<const float*>(rec);
-        const float* rdiag = reinterpret_cast<const float*>(rec + rec_off_diag(N));
-        const int* rcolptr = reinterpret_cast<const int*>(rec + rec_off_colptr(N));
-        const float* rvals = reinterpret_cast<const float*>(rec + rec_off_vals(N));
-        const unsigned char* rrows = rec + rec_off_rows(N, p.cap);
-        if (tid < 256) coef[tid] = tid < N ? r[tid] / rs[tid] : 0.f;
-        __syncthreads();
-        const int j = tid >> 2, q = tid & 3;           // four lanes per column
-        float part = 0.f;
-        if (j < N) {
-            const int e1 = rcolptr[j + 1];
-            for (int e = rcolptr[j] + q; e < e1; e += 4) part += coef[rrows[e]] * rvals[e];
-        }
-        const float p1 = __shfl_xor(part, 1, 64);
-        const float pair = (q & 1) ? p1 + part : part + p1;        // lanes q and q^1 hold the same (even + odd) sum
-        const float p2 = __shfl_xor(pair, 2, 64);
-        const float tot = (q & 2) ? p2 + pair : pair + p2;         // (q0 + q1) + (q2 + q3) on every lane
-        __syncthreads();                               // every read of r (through coef) is done
-        if (j < N && q == 0) r[j] = tot + coef[j] * rdiag[j];
-        if (tid >= 4 * N && tid < 4 * 256 && q == 0) r[j] = 0.f;
-        if (l > 0) sstore(buf ^ 1);                    // (image buf ^ 1 was last read before this iteration's first barrier)
-    }
-    __syncthreads();
-    rollout_emit(p, b, r, vals, sel);
-}
-
 // The discard threshold of ONE layer's head-mean map per sample (the radix select is 90 % of the rollout's time and does not depend
 // on the chain): launched per layer right behind that layer's attn_headmean on the side stream, so that the rollout at the
 // reservation layer -- on the critical path -- is left with the row-vector chain only.  Same select, same key: identical results.
@@ -466,43 +298,6 @@ int ppf_rollout_threshold(const float* hm_layer, int B, int N, int NP, int kdrop
     return 0;
 }
 
-// Column-compressed record of one layer's processed map per sample (see rollout_compact_kernel): bytes per (layer, sample) record, or 0
-// when the form does not apply (no discard, or a record larger than the chain's LDS images).
-size_t ppf_rollout_compact_bytes(int N, int kdrop) {
-    if (N < 2 || N > 16 * RPW || N > 64 * CPL - 1 || kdrop <= 0 || kdrop >= N * N) return 0;
-    const int sz = rec_size(N, N * N - kdrop);
-    return sz <= 2 * NTHR * 16 ? (size_t)sz : 0;
-}
-int ppf_rollout_compact_layer(const float* hm_layer, int B, int N, int NP, int kdrop, float identity, void* recs, hipStream_t stream) {
-    PPF_CHECK_ARG(B >= 1 && NP >= N && hm_layer && recs && ppf_rollout_compact_bytes(N, kdrop) > 0, PPF_ERR_SHAPE,
-                  "ppf_rollout_compact_layer: bad arguments B=%d N=%d NP=%d kdrop=%d", B, N, NP, kdrop);
-    const int cap = N * N - kdrop;
-    hipLaunchKernelGGL(rollout_compact_kernel, dim3(B), dim3(NTHR), 0, stream, hm_layer, N, NP, kdrop, identity, cap, rec_size(N, cap), (unsigned char*)recs);
-    PPF_LAUNCH_CHECK();
-    return 0;
-}
-// ppf_rollout over the records of ppf_rollout_compact_layer (recs: [L][B][ppf_rollout_compact_bytes(N, kdrop)]) instead of the maps.
-int ppf_rollout_compact(const void* recs, int L, int B, int N, const float* init_rows, int n_init, int lead, int kdrop, int kdrop_init,
-                        float identity, int k, float* cls_attn, int* idx, float* policy, hipStream_t stream) {
-    PPF_CHECK_ARG(L >= 1 && B >= 1 && recs && ppf_rollout_compact_bytes(N, kdrop) > 0, PPF_ERR_SHAPE, "ppf_rollout_compact: bad shape L=%d B=%d N=%d kdrop=%d", L, B, N, kdrop);
-    PPF_CHECK_ARG((lead == 1 && init_rows == nullptr) || (lead == 0 && init_rows != nullptr && n_init >= 1), PPF_ERR_ARG,
-                  "ppf_rollout_compact: lead=1 needs no init rows, lead=0 needs them");
-    PPF_CHECK_ARG(k >= 1 && k <= N - lead && kdrop_init >= 0 && kdrop_init <= N, PPF_ERR_ARG, "ppf_rollout_compact: bad k=%d / discard count", k);
-    RolloutParams p;
-    p.hm = nullptr; p.layer_stride = 0; p.L = L; p.B = B; p.N = N; p.NP = N; p.init_rows = init_rows; p.n_init = n_init; p.lead = lead;
-    p.kdrop = kdrop; p.kdrop_init = kdrop_init; p.identity = identity; p.k = k; p.cls_attn = cls_attn; p.idx = idx; p.policy = policy;
-    p.thr = nullptr; p.compact = (const unsigned char*)recs; p.cap = N * N - kdrop; p.rec_bytes = rec_size(N, p.cap);
-    const int lds = 2 * p.rec_bytes;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_chain_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_lds = lds;
-    }
-    hipLaunchKernelGGL(rollout_chain_compact_kernel, dim3(B), dim3(NTHR), lds, stream, p);
-    PPF_LAUNCH_CHECK();
-    return 0;
-}
-
 int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int NP, const float* init_rows, int n_init, int lead,
                 int kdrop, int kdrop_init, float identity, int k, const void* thr_u32, float* cls_attn, int* idx, float* policy,
                 hipStream_t stream) {
@@ -514,7 +309,7 @@ int ppf_rollout(const float* hm, int64_t layer_stride, int L, int B, int N, int 
     RolloutParams p;
     p.hm = hm; p.layer_stride = layer_stride; p.L = L; p.B = B; p.N = N; p.NP = NP; p.init_rows = init_rows; p.n_init = n_init; p.lead = lead;
     p.kdrop = kdrop; p.kdrop_init = kdrop_init; p.identity = identity; p.k = k; p.cls_attn = cls_attn; p.idx = idx; p.policy = policy;
-    p.thr = (const uint32_t*)thr_u32; p.compact = nullptr; p.cap = 0; p.rec_bytes = 0;
+    p.thr = (const uint32_t*)thr_u32;
     hipLaunchKernelGGL(rollout_kernel, dim3(B), dim3(NTHR), 0, stream, p);
     PPF_LAUNCH_CHECK();
     return 0;

@@ -36,12 +36,8 @@
 namespace {
 
 constexpr int RG_BK = 64, RG_S = 2, RG_NTHR = 512;                  // k per stage, LDS slots (double buffer), threads
-#ifndef RG_NT_A
-#define RG_NT_A 1
-#endif
-#ifndef RG_ISSUE_FRAC
-#define RG_ISSUE_FRAC 100                                            // percent of a stage's MFMA stream over which a wave issues its pieces
-#endif
+constexpr bool RG_NT_A = true;                                       // the A pieces (read once) arrive with the non-temporal hint
+constexpr int RG_ISSUE_FRAC = 100;                                   // percent of a stage's MFMA stream over which a wave issues its pieces
 enum RgEpi { RG_BF16 = 0, RG_RESID_LN = 1, RG_LNBWD = 2, RG_LNBWD_LS = 3 };
 
 typedef __attribute__((address_space(3))) void rg_lds_t;
@@ -63,7 +59,6 @@ struct RowGemmParams {
     //           partial[tile][2][n] = sum_m rowscale * dx_out * branch[m][n] (d gamma; branch = the unscaled branch output saved by forward)
     const float* x; const float* mean; const float* rstd; const float* w;
     const float* dres_in; float* dx_out; bf16_t* cast_out; float* partial; const bf16_t* branch;
-    int no_touch;                  // measurement switch (PPF_ROWGEMM_TOUCH=0): no L2 touch-prefetch
 };
 
 // 16-byte chunk c of a 128-byte row r is stored at chunk c ^ swz(r): the four 16-lane groups of a ds_read_b128 (lanes {0-3,12-15,20-27},
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(RG_NTHR, 2) void rowgemm_kernel(const RowGemmParams
             if (r < rows) tsrc = gA + (size_t)r * p.lda * 2;
         }
     }
-    const bool do_touch = tsrc != nullptr && !p.no_touch;
+    const bool do_touch = tsrc != nullptr;
 
     // One stage = 64 contraction values out of slot `slot`; with ISSUE the wave's pieces of the next stage go into the other slot,
     // spread over the MFMA stream: the body is cut into one scheduling region per (k-substep, m-tile) -- sched_barrier pins the
@@ -489,8 +484,6 @@ int ppf_rowgemm_supported(int D, int K, int rows_per_tile) {
 }
 
 static int rg_run(RowGemmParams& p, int D, int epi, hipStream_t stream) {
-    static const int touch = getenv("PPF_ROWGEMM_TOUCH") ? atoi(getenv("PPF_ROWGEMM_TOUCH")) : 1;
-    p.no_touch = !touch;
     PPF_CHECK_ARG(p.M > 0 && ppf_rowgemm_supported(D, p.K, p.rows_per_tile), PPF_ERR_SHAPE,
                   "ppf_rowgemm: unsupported shape M=%d D=%d K=%d rows_per_tile=%d (D in {192, 384}, K %% 64 == 0, rows_per_tile <= 208)", p.M, D, p.K, p.rows_per_tile);
     PPF_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= p.K && p.ldb >= p.K && (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, PPF_ERR_ALIGN,

@@ -87,7 +87,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, epi=EPI_BF16, out=None, bias=Non
 # ------------------------------------------------------------------------------------------------ full-row GEMM + fused LayerNorm
 def rowgemm_ok(D, K, rows_per_tile):
     """True when csrc/rowgemm.hip takes a product with output width D, contraction K and tiles of rows_per_tile rows."""
-    return os.environ.get("PPF_ROWGEMM", "1") != "0" and bool(_lib.lib().ppf_rowgemm_supported(int(D), int(K), int(rows_per_tile)))
+    return bool(_lib.lib().ppf_rowgemm_supported(int(D), int(K), int(rows_per_tile)))
 
 
 _CU_COUNT = {}
@@ -99,13 +99,7 @@ def rowgemm_tile_rows(M, rows_per_sample, device=None, backward=False):
     DropPath scale is indexed by the global row (rows_per_group).
     Forward: half a sample (255 tiles of 99 rows).  backward=True (callers whose side stream is busy with weight-gradient GEMMs while
     these one-per-CU workgroups run): tiles for ~62 % of the CUs, the rest stays free for the side stream -- measured on deit_tiny batch
-    128, img/s: whole samples 24.3k, 144-176 rows 24.9-25.0k, half samples 23.6k.  PPF_ROWGEMM_SPLIT=0 / 2 = never / half samples
-    everywhere; PPF_ROWGEMM_BWD_ROWS=n: explicit backward height (measurement switches)."""
-    mode = os.environ.get("PPF_ROWGEMM_SPLIT", "1")
-    if mode == "0":
-        return rows_per_sample
-    if backward and os.environ.get("PPF_ROWGEMM_BWD_ROWS"):
-        return min(int(os.environ["PPF_ROWGEMM_BWD_ROWS"]), rows_per_sample)
+    128, img/s: whole samples 24.3k, 144-176 rows 24.9-25.0k, half samples 23.6k."""
     dev = torch.cuda.current_device() if device is None else device
     cus = _CU_COUNT.get(dev)
     if cus is None:
@@ -114,7 +108,7 @@ def rowgemm_tile_rows(M, rows_per_sample, device=None, backward=False):
     if 3 * tiles > 2 * cus or rows_per_sample <= 16:
         return rows_per_sample
     half = (rows_per_sample + 1) // 2
-    if backward and mode != "2":
+    if backward:
         target = max(1, int(0.62 * cus))
         return max(half, min(rows_per_sample, (M + target - 1) // target))
     return half
@@ -146,39 +140,6 @@ def rowgemm_resid_ln(a, b, res, rows_per_tile, bias=None, rowscale=None, rows_pe
     _lib.call("ppf_rowgemm_resid_ln", a, b, M, D, K, K, b.shape[1], rows_per_tile, bias, res, xout, rowscale, rows_per_group, colscale, aux_out,
               ln_w, ln_b, n, mean, rstd, float(eps))
     return xout, n, mean, rstd
-
-
-def mlp_fwd_supported(D, hid, rows_per_tile):
-    """True when csrc/mlpfwd.hip takes an MLP of width D / hidden width hid in tiles of rows_per_tile rows."""
-    return bool(_lib.lib().ppf_mlp_fwd_supported(int(D), int(hid), int(rows_per_tile)))
-
-
-def mlp_fwd_ok(D, hid, rows_per_tile):
-    """The train step uses the fused MLP forward only when asked (PPF_MLP_FUSED=1): measured 290-305 us per deit_small layer against 214 us
-    for the two launches it replaces (profiles/r5_mlp_fused.txt) -- correct, tested, and slower."""
-    return os.environ.get("PPF_MLP_FUSED", "0") != "0" and mlp_fwd_supported(D, hid, rows_per_tile)
-
-
-def mlp_fwd(a, w1, b1, w2, b2, res, rows_per_tile, rowscale=None, rows_per_group=1, ln_w=None, ln_b=None, eps=1e-6, colscale=None, aux_out=None):
-    """timm Mlp + residual + the following LayerNorm in one launch (csrc/mlpfwd.hip): h = gelu(a @ w1^T + b1) (bf16, saved for backward),
-    dgelu = gelu'(.) as 8-bit codes, x_out = res + rowscale * colscale * (h @ w2^T + b2) (fp32), n = bf16(LN(x_out)) with mean / rstd.
-    Returns (x_out, n, mean, rstd, h, dgelu) (n, mean, rstd None without a LayerNorm)."""
-    _chk(a, torch.bfloat16), _chk(w1, torch.bfloat16), _chk(w2, torch.bfloat16), _chk(res, torch.float32)
-    M, D = a.shape
-    hid = w1.shape[0]
-    assert w1.shape[1] == D and tuple(w2.shape) == (D, hid), "w1 [hid, D], w2 [D, hid]"
-    dev = a.device
-    h = torch.empty((M, hid), dtype=torch.bfloat16, device=dev)
-    dg = torch.empty((M, hid), dtype=torch.uint8, device=dev)
-    xout = torch.empty((M, D), dtype=torch.float32, device=dev)
-    n = mean = rstd = None
-    if ln_w is not None:
-        n = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
-        mean = torch.empty(M, dtype=torch.float32, device=dev)
-        rstd = torch.empty(M, dtype=torch.float32, device=dev)
-    _lib.call("ppf_mlp_fwd", a, w1, b1, w2, b2, M, D, hid, rows_per_tile, h, dg, res, xout, rowscale, rows_per_group, colscale, aux_out,
-              ln_w, ln_b, n, mean, rstd, float(eps))
-    return xout, n, mean, rstd, h, dg
 
 
 def rowgemm_lnbwd(a, b, x, mean, rstd, w, dw, db, rows_per_tile, dres_in=None, dx_out=None, cast_out=None, rowscale=None, rows_per_group=1,
@@ -236,8 +197,8 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, *, dres_in=None, dx_out=None, ro
     sums = (dw if dy is not None else None, db if dy is not None else None, dbias_next if cast_out is not None else None,
             dcolscale if (cast_out is not None and branch is not None) else None)
     part = None
-    # fixed-order two-pass column sums at every size (bit-identical from run to run); PPF_LN_PARTIAL=0 -> fp32 atomics
-    if any(t is not None for t in sums) and os.environ.get("PPF_LN_PARTIAL", "1") != "0":
+    # fixed-order two-pass column sums at every size (bit-identical from run to run)
+    if any(t is not None for t in sums):
         dev = (dy if dy is not None else dres_in).device
         part = torch.empty(_lib.lib().ppf_layernorm_bwd_blocks(rows) * 4 * D, dtype=torch.float32, device=dev)
     _lib.call("ppf_layernorm_bwd", dy, x, row_map, w, mean, rstd, dres_in, dx_out, dw, db, cast_out, rowscale, rows_per_group,
@@ -282,7 +243,7 @@ def assemble_tokens_bwd(dx, dpos, dcls, B, Np, D, lead):
 
 def attn_fwd_hm_ok(H, N, D):
     """The one-launch forward + head-mean kernel (csrc/attention.hip attn_fwd16_kernel) covers this (heads, tokens, width)."""
-    return os.environ.get("PPF_ATTN_FWD16", "1") != "0" and bool(_lib.lib().ppf_attn_fwd_hm_supported(H, N, D))
+    return bool(_lib.lib().ppf_attn_fwd_hm_supported(H, N, D))
 
 
 def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True, eps_n=0, headmean=None):
@@ -292,7 +253,7 @@ def attn_fwd(qkv, B, H, N, D, policy=None, self_keep=True, eps_n=0, headmean=Non
     out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
     rowmax = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     zinv = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    if headmean is not None or (os.environ.get("PPF_ATTN_FWD16", "1") == "2" and attn_fwd_hm_ok(H, N, D)):
+    if headmean is not None:
         NP = (N + 3) // 4 * 4
         _lib.call("ppf_attn_fwd_hm", qkv, out, policy, rowmax, zinv, headmean, NP, B, H, N, D, int(self_keep), int(eps_n))
     else:
@@ -321,18 +282,6 @@ def rollout_threshold(hm_layer, thr_out, N, discard_ratio=0.9):
     _lib.call("ppf_rollout_threshold", hm_layer, B, N, NP, int(N * N * discard_ratio), thr_out)
 
 
-def rollout_compact_bytes(N, discard_ratio=0.9):
-    """Bytes of one (layer, sample) record of rollout_compact_layer, or 0 when the column-compressed form does not apply."""
-    return int(_lib.lib().ppf_rollout_compact_bytes(N, int(N * N * discard_ratio)))
-
-
-def rollout_compact_layer(hm_layer, recs_layer, N, discard_ratio=0.9, identity=0.2):
-    """recs_layer [B, rollout_compact_bytes(N)] uint8 <- the layer's processed map (discard, +identity, normalisation, row sums) in
-    column-compressed form: everything of the rollout step that does not depend on the chain (side stream, behind the layer's map)."""
-    B, _, NP = hm_layer.shape
-    _lib.call("ppf_rollout_compact_layer", hm_layer, B, N, NP, int(N * N * discard_ratio), float(identity), recs_layer)
-
-
 def rollout_outputs(B, N, k, lead, device):
     """(cls_attn [B,N-lead], idx int32 [B,k], policy [B,N-lead+1]) buffers for rollout(out=...)."""
     Nk = N - lead
@@ -340,19 +289,15 @@ def rollout_outputs(B, N, k, lead, device):
             torch.empty((B, Nk + 1), dtype=torch.float32, device=device))
 
 
-def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None, out=None, compact=None):
+def rollout(hm, L, B, N, k, lead=1, init_rows=None, discard_ratio=0.9, identity=0.2, thr=None, out=None):
     """hm: [L,B,N,NP] fp32 head-mean attention. Returns (cls_attn [B,N-lead], idx int32 [B,k] ascending, policy [B,N-lead+1]);
-    out = rollout_outputs(...) to write into existing buffers (no allocation: usable on the side-stream lane).
-    compact = [L,B,rollout_compact_bytes(N)] records of rollout_compact_layer: the chain reads those instead of hm / thr."""
+    out = rollout_outputs(...) to write into existing buffers (no allocation: usable on the side-stream lane)."""
     _chk(hm, torch.float32)
     NP = hm.shape[-1]
     cls_attn, idx, policy = out if out is not None else rollout_outputs(B, N, k, lead, hm.device)
     n_init = init_rows.shape[0] if init_rows is not None else 0
     # discard counts in double precision, exactly like the reference's int(numel * ratio)
     kdrop, kdrop_init = int(N * N * discard_ratio), int((N + 1) * discard_ratio)
-    if compact is not None:
-        _lib.call("ppf_rollout_compact", compact, L, B, N, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, cls_attn, idx, policy)
-        return cls_attn, idx, policy
     _lib.call("ppf_rollout", hm, B * N * NP, L, B, N, NP, init_rows, n_init, lead, kdrop, kdrop_init, float(identity), k, thr, cls_attn, idx, policy)
     return cls_attn, idx, policy
 
@@ -381,7 +326,7 @@ def proto_bwd(tokens, t0, T, protos, dist, g_full, g_max, argmax, dtok, dprotos,
     P = protos.shape[0]
     if T == 1 and from_act:
         raise ValueError("proto_bwd: from_act applies to the pooled branch (T > 1)")
-    if T == 1 and (g_full is None) != (g_max is None) and os.environ.get("PPF_PROTO_BWD_DENSE", "1") != "0":
+    if T == 1 and (g_full is None) != (g_max is None):
         # one token per sample: every (sample, prototype) pair carries a gradient -> two dense fp32 products instead of the gather
         ws = _workspace(tokens.device, _lib.lib().ppf_proto_bwd_single_workspace(B, P, Dp))
         _lib.call("ppf_proto_bwd_single", tokens, Ttot * Dp, t0, protos, B, P, Dp, act_kind, float(eps), dist, g_max if g_max is not None else g_full,
@@ -627,9 +572,20 @@ def th_dwl(qkv, ds_prime, dwl, B, H, N, D):
     _lib.call("ppf_th_dwl", qkv, ds_prime, dwl, B, H, N, D, ds_prime.shape[-1])
 
 
+def _th_mode():
+    """PPF_TH_FUSED: "1" (default) the fused talking-heads kernels incl. A.V forward and one launch for dQ / dK / dV backward; "pv0" the fused
+    kernels up to A / dS with the per-head products as batched GEMMs; "0" the materialising kernels (what shapes outside the fused kernels'
+    cover get).  The two non-default values exist so that tests/test_gpu_cait.py exercises those fallback kernels at a shape the fused ones cover."""
+    return os.environ.get("PPF_TH_FUSED", "1")
+
+
 def th_fused_ok(H, N, D):
     """The fused talking-heads kernels (csrc/cait.hip th_fwd / th_bwd) cover this (heads, tokens, width)."""
-    return os.environ.get("PPF_TH_FUSED", "1") != "0" and bool(_lib.lib().ppf_th_fused_supported(H, N, D))
+    return _th_mode() != "0" and bool(_lib.lib().ppf_th_fused_supported(H, N, D))
+
+
+def th_pv_fused():
+    return _th_mode() == "1"
 
 
 def th_fwd(qkv, wl, bl, ww, bw, hm_out, B, H, N, D, with_out=True):
@@ -656,7 +612,7 @@ def th_bwd(qkv, dout, wl, bl, ww, rowmax, zinv, B, H, N, D):
 
 
 def th_grads_ok(H, N, D):
-    return os.environ.get("PPF_TH_GRADS", "1") != "0" and bool(_lib.lib().ppf_th_grads_supported(H, N, D))
+    return _th_mode() == "1" and bool(_lib.lib().ppf_th_grads_supported(H, N, D))
 
 
 def th_grads(qkv, dout, ds16, a16, dqkv, B, H, N, D):

@@ -53,7 +53,7 @@ def build_features(base_architecture, pretrained=False, img_size=224, drop_path=
 
 
 # ------------------------------------------------------------------------------------------------ autograd nodes
-_SIDE_FIRST = os.environ.get("PPF_PROTO_SIDE_FIRST", "1") != "0"
+_SIDE_FIRST = True           # the side stream starts on the prototype gradients before the main stream's token-gradient kernels (+1.4 %, round 2)
 _KEEP_DIST = os.environ.get("PPF_PROTO_KEEP_DIST", "0") != "0"      # A/B: write and save the (B,P,k) distance map in training as before round 5
 
 
@@ -61,8 +61,7 @@ _KEEP_DIST = os.environ.get("PPF_PROTO_KEEP_DIST", "0") != "0"      # A/B: write
 # tensor that the prototype-layer backward would scan twice, PPCLossFn.backward hands autograd a zero-stride placeholder of that shape
 # and parks the block rows here, keyed by the placeholder's storage; ProtoLayerFn.backward picks them up (ppf_proto_bwd_rows).  Only taken
 # when the activation map comes straight (through views) from ProtoLayerFn; a gradient that autograd had to combine with another one
-# arrives dense (placeholder zeros + the other gradient) and gets the parked rows added (_rows_for) -- PPF_PROTO_ROWS=0 = always dense.
-_PROTO_ROWS = os.environ.get("PPF_PROTO_ROWS", "1") != "0"
+# arrives dense (placeholder zeros + the other gradient) and gets the parked rows added (_rows_for).
 _PENDING_ROWS = {}
 
 
@@ -84,7 +83,7 @@ def _rows_for(g_full):
         return None, g.reshape(g_full.shape)
     _PENDING_ROWS.clear()
     raise RuntimeError("protopformer_amd: a block-form PPC gradient is parked but the prototype layer received no activation-map gradient "
-                       "to attach it to; set PPF_PROTO_ROWS=0 to exchange dense gradients")
+                       "to attach it to")
 
 
 _ZERO_POOL = {}
@@ -103,7 +102,7 @@ def _check_rows_consumed():
     if _PENDING_ROWS:
         _PENDING_ROWS.clear()
         raise RuntimeError("protopformer_amd: a block-form PPC gradient was produced but no prototype-layer backward consumed it; "
-                           "set PPF_PROTO_ROWS=0 to exchange dense gradients")
+                           "(the activation map was consumed outside ProtoLayerFn)")
 
 
 def _from_proto_layer(t):
@@ -226,7 +225,7 @@ class PPCLossFn(torch.autograd.Function):
         loss, gcov, gmean = ops.ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh)
         ctx.save_for_backward(gcov, gmean, label)
         ctx.shape = act_full.shape
-        ctx.block_rows = _PROTO_ROWS and ppc <= 16 and act.shape[2] >= 2 and _from_proto_layer(act_full)
+        ctx.block_rows = ppc <= 16 and act.shape[2] >= 2 and _from_proto_layer(act_full)
         ctx.set_materialize_grads(False)
         return loss[0], loss[1]
 

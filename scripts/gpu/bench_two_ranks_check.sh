@@ -4,5 +4,5 @@
 # behind the timed region on both ranks (a leg only rank 0 ran would hang here).  ~10 s per step through gloo: 3-4 minutes.
 # Round 5: passed (one JSON line, n_gpus 2, rccl_world 2, named_path present) after the path-probe leg was moved from rank 0 to all ranks.
 cd $GRAFT_REPO_ROOT
-export PPF_BENCH_ONE_GPU=1 PPF_BENCH_BACKEND=gloo
+export PPF_BENCH_ONE_GPU=1
 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 3 --batch 16 --config deit_tiny --no-cpu-baseline --no-secondary | cut -c1-400

@@ -360,17 +360,12 @@ namespace ppfg {
 // Shapes the pipelined kernel takes.  Measured on MI355X (profiles/r1_gemm_nt256.txt): with one workgroup per CU nothing overlaps
 // a tile's output stores, so the kernel only wins where the contraction is long enough to amortise them -- ~1.0 PFLOP/s vs
 // ~0.75 for the 128x128 kernel at K >= 1536, parity at K = 384 -- and where 256-wide tiles waste little of N.
-// PPF_GEMM_NT256 = 0 never, 1 always when legal, unset: the heuristic below.
+// (Retired from libppf_hip.so in round 6: no BASELINE configuration has a K >= 768 forward product; kept here with its own entry point.)
 bool nt256_eligible(const GemmParams& p, int epi) {
-    static const int mode = getenv("PPF_GEMM_NT256") ? atoi(getenv("PPF_GEMM_NT256")) : -1;
-    if (mode == 0) return false;
     if (!(epi == EPI_BF16 || epi == EPI_F32 || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU)) return false;
     if (p.K % (2 * TK) != 0 || p.kpad) return false;                      // an even number of K tiles: buffer parity restarts per tile
     if (p.M < TM || p.N < TN || (long long)p.lda * 256 >= (1ll << 30) || (long long)p.ldb * 256 >= (1ll << 30)) return false;
-    const int tn = (p.N + TN - 1) / TN;
-    const long long tiles = (long long)((p.M + TM - 1) / TM) * tn;
-    if (mode == 1) return true;
-    return tiles >= 192 && p.K >= 768 && (long long)tn * TN * 10 <= (long long)p.N * 11;
+    return true;
 }
 
 int launch_nt256(const GemmParams& p_, int epi, hipStream_t stream) {
@@ -389,3 +384,15 @@ int launch_nt256(const GemmParams& p_, int epi, hipStream_t stream) {
 }
 
 }  // namespace ppfg
+
+// Stand-alone C entry (the product library reached this kernel through ppf_gemm_bf16's dispatcher until round 6):
+// C[M][N] = epilogue(A[M][K] . B[N][K]^T + bias), epi 0 bf16 | 1 fp32 | 2 GELU (+ gelu' codes to aux) | 4 fp32 residual | 5 x gelu' codes from aux
+extern "C" int ppf_gemm_nt256(const void* A, const void* B, void* C, int M, int N, int K, int epi, const float* bias, const float* res, void* aux,
+                              hipStream_t stream) {
+    ppfg::GemmParams p{};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
+    p.bias = bias; p.res = res; p.ldres = N; p.rows_per_group = 1; p.aux_in = (const bf16_t*)aux; p.aux_out = (bf16_t*)aux; p.ldaux = N;
+    p.alpha = 1.0f; p.batch_inner = 1; p.cs_parts = 1; p.nsplit = 1;
+    if (!ppfg::nt256_eligible(p, epi)) return PPF_ERR_SHAPE;
+    return ppfg::launch_nt256(p, epi, stream);
+}

@@ -3,10 +3,14 @@ residual + LayerNorm) at the train step's shapes.  Interleaved rounds in one pro
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(_HERE)))))
+sys.path.insert(0, _HERE)
 import torch
 
 from protopformer_amd import ops
+import mlp_fwd as _X                                   # the retired kernel's own wrapper (build.sh first)
+ops.mlp_fwd, ops.mlp_fwd_supported = _X.mlp_fwd, _X.mlp_fwd_supported
 
 B, N, D = int(os.environ.get("RB_B", 256)), int(os.environ.get("RB_N", 197)), int(os.environ.get("RB_D", 384))
 M, hid = B * N, 4 * D

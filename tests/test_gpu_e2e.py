@@ -380,32 +380,3 @@ def test_reserved_token_compaction_matches_masked_blocks(monkeypatch):
     assert rel_err(a["f"], b["f"]) < 8e-3 and rel_err(a["logits"], b["logits"]) < 4e-4 and abs(a["loss"] - b["loss"]) < 2e-5 * abs(b["loss"])
     cos = float(torch.dot(a["grads"], b["grads"]) / (a["grads"].norm() * b["grads"].norm()))
     assert cos > 0.9998, cos
-
-
-def test_fused_mlp_forward_matches_two_launch_path(monkeypatch):
-    """PPF_MLP_FUSED=1 (csrc/mlpfwd.hip: fc1 -> GELU -> fc2 -> residual -> next LayerNorm in one launch, opt-in) through the whole train-mode
-    forward + backward of a deit_tiny PPNet: same reserved tokens, logits, loss and gradients as the default fc1 GEMM + full-row fc2 GEMM
-    up to the rounding of a differently ordered fp32 accumulation (h and gelu' differ in < 2 % of their bf16 / 8-bit codes by one step)."""
-    from protopformer_amd.protopformer import CrossEntropyLoss, construct_PPNet
-    g = torch.Generator().manual_seed(12)
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("PPF_MLP_FUSED", mode)
-        torch.manual_seed(3)
-        m = construct_PPNet("deit_tiny_patch16_224", pretrained=False, prototype_shape=(200, 64, 1, 1), num_classes=20, reserve_layers=[10],
-                            reserve_token_nums=[81], use_global=True, use_ppc_loss=True, global_proto_per_class=5, add_on_layers_type="regular").cuda().train()
-        for blk in m.features.blocks:
-            blk.drop_path_rate = 0.0
-        if "img" not in res:
-            res["img"] = torch.randn(4, 3, 224, 224, generator=g).cuda(); res["label"] = torch.tensor([3, 0, 19, 7]).cuda()
-        logits, aux = m(res["img"])
-        ce = CrossEntropyLoss()(logits, res["label"])
-        cov, mean = m.get_PPC_loss(aux[2], aux[3], aux[4], res["label"])
-        (ce + 0.1 * cov + 0.5 * mean).backward()
-        res[mode] = dict(idx=m._ppc_cache[1].clone(), logits=logits.detach().clone(), loss=float(ce.detach()), grads=m.flat_store().grads.clone())
-    a, b = res["1"], res["0"]
-    cos = float(torch.dot(a["grads"], b["grads"]) / (a["grads"].norm() * b["grads"].norm()))
-    report("fused_mlp_vs_two_launches_tiny", logits=rel_err(a["logits"], b["logits"]), loss=abs(a["loss"] - b["loss"]) / abs(b["loss"]), cos=cos,
-           reserved_differing=int((a["idx"] != b["idx"]).sum()))
-    assert rel_err(a["logits"], b["logits"]) < 1e-3 and abs(a["loss"] - b["loss"]) < 1e-4 * abs(b["loss"]) and cos > 0.9995, (rel_err(a["logits"], b["logits"]), cos)
-

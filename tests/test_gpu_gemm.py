@@ -27,6 +27,31 @@ def test_gemm_nt_bf16_and_f32(M, N, K):
     assert_close(out16.float(), ref.bfloat16().float(), rtol=8e-3, atol=1e-3, what="gemm bf16 out")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(24576, 512, 1024, "bf16"), (24600, 520, 768, "resid"), (24576, 512, 768, "gelu"), (25000, 512, 896, "dgelu")])
+def test_gemm_long_contraction_forward_shapes(M, N, K, epi):
+    """K >= 768 forward products (deit_base; no BASELINE configuration) through the dispatcher: edge tiles in m and n, odd K-tile counts, every
+    fused epilogue, 10 bit-identical repeats.  Until round 6 these went to the 256x256 kernel (now scripts/gpu/experiments/gemm_nt256); the
+    128x128 / 224x128 kernels serve them since."""
+    from protopformer_amd import ops
+    a = _mk((M, K), 0.5, 1).bfloat16(); b = _mk((N, K), 0.05, 2).bfloat16(); bias = _mk((N,), 0.1, 3)
+    pre = a.float() @ b.float().t()
+    if epi == "bf16":
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_BF16, bias=bias); ref = (pre + bias); tol = dict(rtol=8e-3, atol=2e-3)
+    elif epi == "resid":
+        res = _mk((M, N), 1.0, 4)
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_RESID, bias=bias, res=res); ref = res + pre + bias; tol = dict(rtol=1e-3, atol=2e-3)
+    elif epi == "gelu":
+        aux = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_GELU, bias=bias, aux_out=aux); ref = torch.nn.functional.gelu(pre + bias); tol = dict(rtol=8e-3, atol=2e-3)
+    else:
+        gp = gelu8_encode(0.5 + _mk((M, N), 0.3, 5))
+        run = lambda: ops.gemm(a, b, epi=ops.EPI_DGELU, aux_in=gp); ref = pre * gelu8_decode(gp); tol = dict(rtol=1e-2, atol=3e-3)
+    out = run()
+    assert_close(out.float(), ref, what=f"long-K {epi}", **tol)
+    for _ in range(10):
+        assert torch.equal(out, run())
+
+
 def test_gemm_transpose_detecting():
     """Asymmetric operands: an (m,n)-swapped write or a k-permutation mismatch between A and B cannot pass."""
     from protopformer_amd import ops
@@ -94,30 +119,6 @@ def test_gemm_wgrad_tn_atomic(R, N, K):
     assert_close(dw, 2 * ref, rtol=1e-3, atol=2e-3 * scale, what="wgrad accumulate")
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(24576, 512, 1024, "bf16"), (24600, 520, 768, "resid"), (24576, 512, 768, "gelu"), (25000, 512, 896, "dgelu")])
-def test_gemm_nt256_pipelined(M, N, K, epi):
-    """Shapes the dispatcher routes to the 256x256 global_load_lds kernel (gemm_nt256.hip): edge tiles in m and n, odd K-tile
-    counts, every fused epilogue; 10 repeats must be bit-identical (the pipeline's counted waits are race-free)."""
-    from protopformer_amd import ops
-    a = _mk((M, K), 0.5, 1).bfloat16(); b = _mk((N, K), 0.05, 2).bfloat16(); bias = _mk((N,), 0.1, 3)
-    pre = a.float() @ b.float().t()
-    if epi == "bf16":
-        run = lambda: ops.gemm(a, b, epi=ops.EPI_BF16, bias=bias); ref = (pre + bias); tol = dict(rtol=8e-3, atol=2e-3)
-    elif epi == "resid":
-        res = _mk((M, N), 1.0, 4)
-        run = lambda: ops.gemm(a, b, epi=ops.EPI_RESID, bias=bias, res=res); ref = res + pre + bias; tol = dict(rtol=1e-3, atol=2e-3)
-    elif epi == "gelu":
-        aux = torch.empty(M, N, dtype=torch.uint8, device="cuda")
-        run = lambda: ops.gemm(a, b, epi=ops.EPI_GELU, bias=bias, aux_out=aux); ref = torch.nn.functional.gelu(pre + bias); tol = dict(rtol=8e-3, atol=2e-3)
-    else:
-        gp = gelu8_encode(0.5 + _mk((M, N), 0.3, 5))
-        run = lambda: ops.gemm(a, b, epi=ops.EPI_DGELU, aux_in=gp); ref = pre * gelu8_decode(gp); tol = dict(rtol=1e-2, atol=3e-3)
-    out = run()
-    assert_close(out.float(), ref, what=f"nt256 {epi}", **tol)
-    for _ in range(10):
-        assert torch.equal(out, run())
-
-
 def test_gemm_wgrad_train_step_shapes():
     """The weight-gradient path at the train step's shapes (scripts/gpu/wgrad_check.py): fp32 reference agreement, bias-gradient column
     sums, bit-identical repeats."""
@@ -130,9 +131,8 @@ def test_gemm_wgrad_train_step_shapes():
     assert float(lines[-1].split()[-1]) < 1e-4, r.stdout
 
 
-_G224_CHILD = r"""
-import sys, torch
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+_G224_CHILD = r"""# (run in-process by test_gemm_224_row_tiles_nt with the library's test hook set)
+import torch
 from helpers import assert_close
 from protopformer_amd import ops
 def mk(shape, scale, seed):
@@ -156,15 +156,22 @@ print("G224 OK")
 
 
 def test_gemm_224_row_tiles_nt():
-    """gemm224g_kernel (224 x 128 direct-to-LDS tiles: the input gradients with the transposed weight shadow).  PPF_GEMM_G224=2 forces it
-    for EVERY eligible shape, which needs a child process (the switch is read once): bf16 output vs an fp32 reference at the train step's
-    shapes, edge tiles in m, ragged n (N = 392 / 136 / 8: the clamped B rows and the n < N store mask), a transpose-detecting pattern,
-    bit-identical repeats.  The default cost model's choice for the step's shapes is covered in-process below."""
-    import os, subprocess, sys
+    """gemm224g_kernel (224 x 128 direct-to-LDS tiles: the input gradients with the transposed weight shadow), forced for EVERY legal shape
+    through the library's test hook (ppf_gemm_test_force_g224): bf16 output vs an fp32 reference at the train step's shapes, edge tiles in
+    m, ragged n (N = 392 / 136 / 8: the clamped B rows and the n < N store mask), a transpose-detecting pattern, bit-identical repeats.  The
+    default cost model's choice for the step's shapes is covered below."""
+    import os
+    from protopformer_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PPF_GEMM_G224="2")
-    r = subprocess.run([sys.executable, "-c", _G224_CHILD, root], capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and "G224 OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    _lib.call("ppf_gemm_test_force_g224", 1)
+    try:
+        import io, contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            exec(compile(_G224_CHILD, "<g224>", "exec"), {"__name__": "__g224__", "_ROOT": root})
+        assert "G224 OK" in buf.getvalue(), buf.getvalue()[-1500:]
+    finally:
+        _lib.call("ppf_gemm_test_force_g224", 0)
 
 
 @pytest.mark.parametrize("M,N,K", [(50432, 384, 1536), (50432, 384, 384)])

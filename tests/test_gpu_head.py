@@ -72,54 +72,6 @@ def test_rollout_with_precomputed_thresholds_is_identical():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B,N,L,k", [(3, 17, 2, 9), (2, 65, 3, 16), (5, 197, 11, 81), (4, 196, 6, 121)])
-def test_rollout_column_compressed_chain(B, N, L, k):
-    """ppf_rollout_compact_layer per layer (side stream in the model) + ppf_rollout_compact == the dense chain: same reserved indices and
-    policy, class attention to summation-order rounding; records rebuilt twice are bit-identical (integer atomics only)."""
-    from protopformer_amd import ops
-    g = torch.Generator().manual_seed(N + L)
-    fused = torch.softmax(3.0 * torch.randn(L, B, N, N, generator=g), dim=-1)
-    hm = _pad_hm(fused)
-    ref = ops.rollout(hm, L, B, N, k, lead=1)
-    rb = ops.rollout_compact_bytes(N)
-    assert rb > 0
-    recs = torch.zeros((L, B, rb), dtype=torch.uint8, device="cuda"); recs2 = torch.zeros_like(recs)
-    for l in range(L):
-        ops.rollout_compact_layer(hm[l], recs[l], N)
-        ops.rollout_compact_layer(hm[l], recs2[l], N)
-    assert torch.equal(recs, recs2)
-    got = ops.rollout(hm, L, B, N, k, lead=1, compact=recs)
-    assert_close(got[0], ref[0], rtol=1e-5, atol=1e-9, what="cls attention, compact vs dense chain")
-    assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
-    # against the oracle's full matrix chain
-    R = O.deit_rollout([fused[l][:, None] for l in range(L)])
-    assert_close(got[0], R[:, 0, 1:], rtol=1e-3, atol=1e-8, what="cls attention, compact chain vs oracle")
-    _check_topk(got[1].cpu().long(), R[:, 0, 1:], k)
-
-
-def test_rollout_goldens_through_the_compact_chain():
-    from protopformer_amd import ops
-    z = load_npz("ops_real.npz")
-    probs = gi.rollout_inputs()
-    hm = _pad_hm(torch.stack([p.mean(1) for p in probs]))
-    recs = torch.empty((11, 2, ops.rollout_compact_bytes(197)), dtype=torch.uint8, device="cuda")
-    for l in range(11):
-        ops.rollout_compact_layer(hm[l], recs[l], 197)
-    cls_attn, idx, policy = ops.rollout(hm, 11, 2, 197, 81, lead=1, compact=recs)
-    assert_close(cls_attn, z["rollout/cls_token_attn"], rtol=1e-3, atol=1e-8, what="cls_token_attn vs reference (compact chain)")
-    assert np.array_equal(idx.cpu().numpy(), z["rollout/idx"]), "reserved-token indices must be bit-exact"
-    c = gi.cait_inputs()
-    hm = _pad_hm(torch.stack([p.mean(1) for p in c["sa"]]))
-    init = torch.stack([p.mean(1)[:, 0] for p in c["cas"]]).cuda().contiguous()
-    recs = torch.empty((4, c["B"], ops.rollout_compact_bytes(c["N"])), dtype=torch.uint8, device="cuda")
-    for l in range(4):
-        ops.rollout_compact_layer(hm[l], recs[l], c["N"])
-    cls_attn, idx, _ = ops.rollout(hm, 4, c["B"], c["N"], 121, lead=0, init_rows=init, compact=recs)
-    ref = torch.from_numpy(z["cait/rollout_cls"])
-    assert_close(cls_attn, ref, rtol=1e-3, atol=1e-8, what="cait cls rollout vs reference (compact chain)")
-    assert torch.equal(idx.cpu().long(), O.topk_sorted(ref, 121))
-
-
 def test_rollout_cait_golden():
     from protopformer_amd import ops
     z = load_npz("ops_real.npz")
