@@ -288,11 +288,14 @@ __global__ __launch_bounds__(F16_NTHR, 1) void attn_fwd16_kernel(const AttnParam
         dst_off[i] = j * 1024;
     }
     const unsigned char* gbase = reinterpret_cast<const unsigned char*>(p.qkv + (size_t)b * N * p.ld);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(lds16));
+    // (issued through inline assembly, see lds_dma16_hidden: with the builtin the compiler drained head h + 1's pieces in front of head h's
+    //  transposed V reads -- the prefetch only covered the Q.K^T + softmax phase)
     auto issue = [&](int h, int buf) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             if (wave + F16_WAVES * i < NPIECE)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(gbase + src_off[i] + h * HD * 2), (lds_void*)(lds16 + buf * BUF + dst_off[i]), 16, 0, 0);
+                lds_dma16_hidden(gbase + src_off[i] + h * HD * 2, lds_base + buf * BUF + __builtin_amdgcn_readfirstlane(dst_off[i]));
     };
     issue(0, 0);
     for (int i = tid; i < ROWS; i += F16_NTHR) pol[i] = (i < N) ? (p.policy ? p.policy[(size_t)b * N + i] : 1.0f) : 0.0f;
@@ -775,6 +778,7 @@ __global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnP
     const int row = r0 + l31, rc = min(row, N - 1);
     unsigned char* scr = scr_all + wave * 4096;
     const float sc2 = p.scale * LOG2E;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
 
     // LDS-DMA pieces of this wave: piece j = wave + NT i, i < 4: rows 8 j .. 8 j + 7 of the Q image, i >= 4: of the dO image; lane l
     // carries row (l >> 3), LDS chunk slot (l & 7) whose SOURCE chunk is slot ^ kswz(row).  (Offsets are recomputed per item: eight
@@ -787,7 +791,9 @@ __global__ __launch_bounds__(NT * 64, 2) void attn_bwd_stream_kernel(const AttnP
         for (int i = 0; i < PPW; ++i) {
             const int j = wave + NT * (i & 3), r = j * 8 + (lane >> 3);
             const int off = min(r, N - 1) * (i < 4 ? p.ld : p.D) * 2 + (((lane & 7) ^ kswz(r)) << 4);
-            __builtin_amdgcn_global_load_lds((gbl_void*)((i < 4 ? qb : ob) + off), (lds_void*)(lds + (i < 4 ? 0 : TILE) + j * 1024), 16, 0, 0);
+            // (hidden from the compiler's wait-count pass, see lds_dma16_hidden: with the builtin it put s_waitcnt vmcnt(0) between the issue of
+            //  item i + 1's images and the stores of item i's results -- the overlap this kernel is built around never happened)
+            lds_dma16_hidden((i < 4 ? qb : ob) + off, lds_base + (i < 4 ? 0 : TILE) + j * 1024);
         }
     };
     // rows of the wave's own tile, MFMA fragment layout (lane -> row l31, 8 values at d = 16 ks + 8 hh): K, V (key tile), O (query tile,

@@ -120,6 +120,19 @@ __device__ __forceinline__ void gelu_erf_both2(ppf_float2 x, ppf_float2& g, ppf_
     d = x * (0.39894228040143267794f * e) + cdf;
 }
 
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KiB of LDS at `lds_addr`, wave-uniform) issued through inline assembly.
+// Why not __builtin_amdgcn_global_load_lds: the compiler's wait-count pass knows that builtin writes LDS asynchronously and puts
+// `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot prove disjoint from it -- every ds_read_tr builtin (no memory operand) and
+// reads through another pointer into the same dynamic-LDS array.  In attn_fwd16_kernel that drained the NEXT head's K / V before the P.V phase of
+// the current one, in attn_bwd_stream_kernel the next item's images before the current item's results were stored (round 6, found in the
+// disassembly: scripts/isa_count.py / profiles/r6_lds_dma_hidden.txt).  The kernels that use this order the DMA against their LDS reads themselves
+// (s_waitcnt vmcnt + barrier).  The compiler's own vmcnt bookkeeping for ordinary loads stays safe: loads return in order, so operations it does
+// not know about only make its counted waits stricter.
+__device__ __forceinline__ void lds_dma16_hidden(const void* gptr, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) { return (uint32_t)(uintptr_t)p; }      // flat LDS address: aperture | offset
+
 // Bijective XCD-aware remap of a 1-D block id: consecutive virtual ids land on the same XCD (private L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;

@@ -309,7 +309,11 @@ class GradSync:
     def _exchange(self, lo, hi):
         """The collective of one chunk on the CURRENT torch stream (the communication stream when there is one)."""
         if self.wire is None:
-            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            w = dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            if os.environ.get("PPF_GS_PENDING", "0") != "0":      # (measurement, removed after the A/B: the pre-round-6 form -- wait in finish())
+                self.pending.append(w)
+            else:
+                w.wait()                                          # NCCL: the communication stream waits for the collective (no host block)
             return
         if self.cuda and (lo % 8 or hi % 8):
             raise ValueError("GradSync bf16 payload: chunk bounds must be multiples of 8 elements (FlatStore segments are)")

@@ -62,6 +62,7 @@ _KEEP_DIST = os.environ.get("PPF_PROTO_KEEP_DIST", "0") != "0"      # A/B: write
 # and parks the block rows here, keyed by the placeholder's storage; ProtoLayerFn.backward picks them up (ppf_proto_bwd_rows).  Only taken
 # when the activation map comes straight (through views) from ProtoLayerFn; a gradient that autograd had to combine with another one
 # arrives dense (placeholder zeros + the other gradient) and gets the parked rows added (_rows_for).
+_PROTO_ROWS = True          # (module attribute, no environment switch: tests/test_gpu_train_state.py sets it to False to get the dense exchange as the referee)
 _PENDING_ROWS = {}
 
 
@@ -225,7 +226,7 @@ class PPCLossFn(torch.autograd.Function):
         loss, gcov, gmean = ops.ppc_loss(act, idx, label, ppc, side, cov_thresh, mean_thresh)
         ctx.save_for_backward(gcov, gmean, label)
         ctx.shape = act_full.shape
-        ctx.block_rows = ppc <= 16 and act.shape[2] >= 2 and _from_proto_layer(act_full)
+        ctx.block_rows = _PROTO_ROWS and ppc <= 16 and act.shape[2] >= 2 and _from_proto_layer(act_full)
         ctx.set_materialize_grads(False)
         return loss[0], loss[1]
 
