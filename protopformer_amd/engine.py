@@ -429,7 +429,7 @@ def make_grad_sync(ppnet, optimizer=None, n_chunks=None, cuts=None, payload=None
     st = ppnet.flat_store()
     env = os.environ.get("PPF_GRADSYNC_CUTS")
     if cuts is None and env:
-        cuts = [int(v) for v in env.split(",") if v.strip()]
+        cuts = [int(v) for v in env.replace("+", ",").split(",") if v.strip()]
     bounds, block_chunk = chunk_plan([(name, o) for name, p, o, n in st.entries], st.total, cuts=cuts, n_chunks=n_chunks)
     sync = GradSync(st.grads, bounds, payload=payload)
     sync.block_chunk = block_chunk                    # chunk that becomes complete when block i's backward has been enqueued (it STARTS at block i)
