@@ -309,11 +309,7 @@ class GradSync:
     def _exchange(self, lo, hi):
         """The collective of one chunk on the CURRENT torch stream (the communication stream when there is one)."""
         if self.wire is None:
-            w = dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-            if os.environ.get("PPF_GS_PENDING", "0") != "0":      # (measurement, removed after the A/B: the pre-round-6 form -- wait in finish())
-                self.pending.append(w)
-            else:
-                w.wait()                                          # NCCL: the communication stream waits for the collective (no host block)
+            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))      # waited for in finish()
             return
         if self.cuda and (lo % 8 or hi % 8):
             raise ValueError("GradSync bf16 payload: chunk bounds must be multiples of 8 elements (FlatStore segments are)")
@@ -408,21 +404,22 @@ def broadcast_replica_state(ppnet, optimizer=None, src=0):
 
 
 def readiness_cuts(depth):
-    """Blocks at which a new gradient chunk starts.  Backward completes the blocks depth-1 .. 0, and the weight-gradient lane lags the
-    main chain, so what becomes ready LAST is what the optimizer waits for: the chunks shrink geometrically towards block 0
-    (depth 12 -> cuts {1, 2, 4, 8}: [b8..b11] | [b4..b7] | [b2, b3] | [b1] | [embedding + b0]) -- the exchange of the large early chunks hides
-    under the rest of backward and the exposed tail is one block + the embedding (8.6 of 93.4 MB at deit_small)."""
-    cuts, c = [], 1
-    while c < depth:
-        cuts.append(c)
-        c *= 2
-    return cuts
+    """Blocks at which a new gradient chunk starts.  Backward completes the blocks depth-1 .. 0 and the weight-gradient lane lags the main chain,
+    so the chunk that becomes ready LAST is the one whose exchange the optimizer waits for: it is made the smallest -- block 0 + the embedding
+    (8.6 of 93.4 MB at deit_small) -- and the rest of the blocks is cut in two: [final norm + heads] | [upper half] | [blocks 1 .. half) |
+    [embedding + block 0].  Measured on one MI355X (profiles/r6_gradsync.txt): every collective costs ~0.25 % of the step on the launch side even with
+    zero link time, so FEW chunks; the r5 partition (three equal block groups) left 29.9 MB to exchange after the last backward kernel (modelled
+    193 us = 1.3 % of the step at 8 GPUs), this one leaves it 0.07 ms of slack with the same number of collectives.  A finer geometric split
+    ({1, 2, 4, 8}) hides no more and costs +0.5 %."""
+    if depth < 2:
+        return []
+    return sorted({1, (depth + 1) // 2})
 
 
 def make_grad_sync(ppnet, optimizer=None, n_chunks=None, cuts=None, payload=None):
     """Chunk the flat gradient in backward-completion order: [heads + norm | late blocks | ... | block 1 | embedding + block 0], after making
     the replicas identical (rank-0 broadcast of parameters, frozen tensors and optimizer state).
-    cuts: block indices that start a chunk (default readiness_cuts(depth); PPF_GRADSYNC_CUTS="8,4" overrides); n_chunks: the pre-round-6
+    cuts: block indices that start a chunk (default readiness_cuts(depth); PPF_GRADSYNC_CUTS="8,4" or "8+4" overrides); n_chunks: the pre-round-6
     equal partition into n_chunks - 1 block groups (kept for A/B)."""
     ppnet = _unwrap(ppnet)
     broadcast_replica_state(ppnet, optimizer)

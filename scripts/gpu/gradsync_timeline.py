@@ -5,9 +5,10 @@ list; GradSync._exchange is wrapped with timing events on the communication stre
 writes the chunk) and `done`; `bwd_end` is recorded on the main stream where finish() starts waiting.  With one rank the collective itself
 is empty, so `ready` times are exactly the hardware readiness of the chunks; the 8-GPU exposure is then MODELLED: chunk exchanges are
 serialised on the communication stream, each takes ALPHA + bytes / ALGBW (ring all-reduce over xGMI: ALGBW = busbw * n / (2 (n - 1))),
-exposed time = completion of the last chunk - bwd_end.  Partitions compared: the pre-round-6 equal blocks (n_chunks = 4), the readiness
-cuts (default), each with fp32 and bf16 payload.
-    python scripts/gpu/gradsync_timeline.py [config] [busbw GB/s] [alpha us]"""
+exposed time = completion of the last chunk - bwd_end.  ONE partition per process (a second model in the same process measured 30 % slower
+steps, whatever its partition): PLAN = equal (the pre-round-6 three equal block groups) | default (engine.readiness_cuts) | a cut list "1+2+4+8";
+PAYLOAD = fp32 | bf16.
+    python scripts/gpu/gradsync_timeline.py PLAN PAYLOAD [config] [busbw GB/s] [alpha us]"""
 import json
 import os
 import sys
@@ -25,9 +26,11 @@ import bench
 from protopformer_amd import backbone, engine
 from protopformer_amd.engine import ReplayedTrainStep
 
-name = sys.argv[1] if len(sys.argv) > 1 else "deit_small"
-BUSBW = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0           # GB/s, large-message ring all-reduce on 8 GPUs (7 xGMI links x 153 GB/s per GPU)
-ALPHA = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0            # us per collective (launch + 2 (n - 1) hops)
+PLAN = sys.argv[1] if len(sys.argv) > 1 else "default"
+PAYLOAD = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+name = sys.argv[3] if len(sys.argv) > 3 else "deit_small"
+BUSBW = float(sys.argv[4]) if len(sys.argv) > 4 else 300.0           # GB/s, large-message ring all-reduce on 8 GPUs (7 xGMI links x 153 GB/s per GPU)
+ALPHA = float(sys.argv[5]) if len(sys.argv) > 5 else 30.0            # us per collective (launch + 2 (n - 1) hops)
 NGPU = 8
 cfg = bench.CONFIGS[name]
 dev = torch.device("cuda", 0)
@@ -108,9 +111,7 @@ def measure(label, payload, **plan):
     return dict(label=label, payload=payload, step_ms=tot / steps, exposed_us=exposed * 1e3, chunks=out)
 
 
-res = [measure("equal blocks (r5: n_chunks=4)", "fp32", n_chunks=4),
-       measure("readiness cuts (r6 default)", "fp32"),
-       measure("readiness cuts (r6 default)", "bf16"),
-       measure("equal blocks (r5: n_chunks=4)", "bf16", n_chunks=4)]
+plan = dict(n_chunks=4) if PLAN == "equal" else ({} if PLAN == "default" else dict(cuts=[int(v) for v in PLAN.split("+")]))
+res = measure(f"plan {PLAN}", PAYLOAD, **plan)
 print("GRADSYNC_TIMELINE " + json.dumps(res))
 dist.destroy_process_group()

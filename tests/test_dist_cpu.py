@@ -70,21 +70,23 @@ def test_grad_sync_single_process_is_noop():
 
 
 def test_chunk_plan_orders_by_readiness():
-    """make_grad_sync's chunk boundaries (engine.chunk_plan, pure): chunks shrink towards block 0, which backward finishes last -- the
-    exposed tail of the exchange is [embedding + block 0], the first chunk to go is [final norm + heads]."""
+    """make_grad_sync's chunk boundaries (engine.chunk_plan, pure): the chunk that backward completes LAST -- [embedding + block 0] -- is the
+    smallest block chunk, the first to go is [final norm + heads]; four chunks (every collective costs launch time)."""
     from protopformer_amd.engine import chunk_plan, readiness_cuts
-    assert readiness_cuts(12) == [1, 2, 4, 8] and readiness_cuts(24) == [1, 2, 4, 8, 16] and readiness_cuts(2) == [1] and readiness_cuts(1) == []
+    assert readiness_cuts(12) == [1, 6] and readiness_cuts(24) == [1, 12] and readiness_cuts(2) == [1] and readiness_cuts(1) == []
     ents, off = [("features.cls_token", 0), ("features.pos_embed", 8), ("features.patch_embed.proj.weight", 100)], 1000
     for i in range(12):
         ents += [(f"features.blocks.{i}.norm1.weight", off), (f"features.blocks.{i}.attn.qkv.weight", off + 8)]
         off += 1000
     ents += [("features.norm.weight", off), ("prototype_vectors", off + 16)]
     bounds, block_chunk = chunk_plan(ents, off + 500)
-    assert bounds == [0, 2000, 3000, 5000, 9000, 13000, 13500]
-    assert block_chunk == {1: 1, 2: 2, 4: 3, 8: 4}               # block i done -> the chunk that starts at block i is complete
+    assert bounds == [0, 2000, 7000, 13000, 13500]
+    assert block_chunk == {1: 1, 6: 2}                            # block i done -> the chunk that starts at block i is complete
     sizes = [b - a for a, b in zip(bounds, bounds[1:])]
-    assert sizes[1:5] == sorted(sizes[1:5])                       # block chunks grow with the block index: the last ready is the smallest
+    assert sizes[0] == min(sizes[:3])                             # the chunk ready last is the smallest of the block chunks
     b4, bc4 = chunk_plan(ents, off + 500, n_chunks=4)             # the pre-round-6 equal partition, kept for A/B
     assert b4 == [0, 5000, 9000, 13000, 13500] and bc4 == {4: 1, 8: 2}
+    bg, bcg = chunk_plan(ents, off + 500, cuts=[1, 2, 4, 8])      # an explicit (geometric) partition
+    assert bg == [0, 2000, 3000, 5000, 9000, 13000, 13500] and bcg == {1: 1, 2: 2, 4: 3, 8: 4}
     b2, bc2 = chunk_plan(ents, off + 500, cuts=[6, 0, 12, 99])    # out-of-range cuts are dropped
     assert b2 == [0, 7000, 13000, 13500] and bc2 == {6: 1}

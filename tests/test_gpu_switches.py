@@ -66,8 +66,8 @@ def test_gradsync_switches_single_rank_rccl():
     base = _run("deit")
     f = _run("deit", PPF_FORCE_GRADSYNC="1")
     assert f["collectives"] >= 2 * f["chunks"] and f["payload"] == "fp32" and f["losses"] == base["losses"] and f["checksum"] == base["checksum"]
-    c = _run("deit", PPF_FORCE_GRADSYNC="1", PPF_GRADSYNC_CUTS="1")
-    assert c["chunks"] == 3 and c["chunks"] != f["chunks"] and c["losses"] == base["losses"] and c["checksum"] == base["checksum"]
+    c = _run("deit", PPF_FORCE_GRADSYNC="1", PPF_GRADSYNC_CUTS="1+2+3")
+    assert c["chunks"] == 5 and c["chunks"] != f["chunks"] and c["losses"] == base["losses"] and c["checksum"] == base["checksum"]
     b = _run("deit", PPF_FORCE_GRADSYNC="1", PPF_GRADSYNC_BF16="1")
     assert b["payload"] == "bf16" and b["losses"][0] == base["losses"][0] and _close(b, base, 2e-3) and b["checksum"] != base["checksum"]
 
