@@ -39,7 +39,11 @@ int ppf_abi_version(void);
 int ppf_device_info(int* cu_count, int* clock_mhz, char* name, int name_len);
 /* stream ordering for the two-lane schedule of the host mirror (weight gradients / head-mean maps / prototype gradients on a side
  * stream): pooled, timing-disabled events inside the library; one call per dependency.
- * wait_stream: everything on src so far happens-before later work on dst.  mark / wait_mark: a ticket for "src so far". */
+ * wait_stream: everything on src so far happens-before later work on dst.  mark / wait_mark: a ticket for "src so far".
+ * arm (round 6): while a stream is armed (on = 1) every kernel the library launches on it carries its own completion event
+ * (hipExtLaunchKernel stop event), and the next wait_stream(dst, stream) waits for the last of them instead of recording an event --
+ * no packet enters the producer's queue.  Armed by the replay loop around the one library call that precedes a wait. */
+int ppf_stream_arm(ppf_stream_t stream, int on);
 int ppf_stream_wait_stream(ppf_stream_t dst, ppf_stream_t src);
 int64_t ppf_stream_mark(ppf_stream_t stream);
 int ppf_stream_wait_mark(ppf_stream_t stream, int64_t ticket);

@@ -312,6 +312,10 @@ def cait_backward(ppnet, store, saved, df):
     du3 = du.reshape(B, N1, D)
     du2 = du.reshape(B, N1 * D)
     dcls = ops.copy_2d(torch.empty((B, D), dtype=torch.float32, device=dev), du2[:, :D])
+    gs = getattr(ppnet, "_grad_sync", None)            # data-parallel: the final norm + add-on + prototype gradients are complete (round 6: this
+    if gs is not None:                                 # chunk was launched LAST, 45 us of exchange behind the last backward kernel)
+        lane.flush()
+        _lib.run_live(lambda: gs.chunk_ready(gs.tail_chunk, also=lane.streams))
     # ---- class-attention blocks (reverse)
     for j in range(len(ca) - 1, -1, -1):
         L, blk = ca[j], feats.blocks_token_only[j]
@@ -348,7 +352,6 @@ def cait_backward(ppnet, store, saved, df):
     last = feats.blocks[-1]
     lnb(None, None, None, None, None, None, None, dres_in=dx, cast_out=dyb, rowscale=sa[-1]["s2"], rows_per_group=N,
                       colscale=last.gamma_2, dbias_next=gv(last.mlp.fc2.bias), branch=sa[-1]["raw2"], dcolscale=gv(last.gamma_2))
-    gs = getattr(ppnet, "_grad_sync", None)
     # Input gradient of fc1 / qkv + LayerNorm backward + LayerScale terms of the branch below as one full-row kernel (csrc/rowgemm.hip,
     # RG_LNBWD_LS) where the shape is covered.  Half-sample tiles as in the forward pass (measured on this backbone, same box: 8 885 vs
     # 8 300 img/s with whole samples -- the opposite of deit_tiny, whose side stream carries relatively more weight-gradient work).
@@ -425,8 +428,6 @@ def cait_backward(ppnet, store, saved, df):
     if gs is not None:
         lane.flush()
         _lib.run_live(lambda: gs.chunk_ready(gs.head_chunk, also=lane.streams))
-        lane.flush()
-        _lib.run_live(lambda: gs.chunk_ready(gs.tail_chunk, also=lane.streams))
     lane.join()
 
 

@@ -133,6 +133,26 @@ __device__ __forceinline__ void lds_dma16_hidden(const void* gptr, uint32_t lds_
 }
 __device__ __forceinline__ uint32_t lds_offset_of(const void* p) { return (uint32_t)(uintptr_t)p; }      // flat LDS address: aperture | offset
 
+// ---- kernel launches that carry their own completion event (round 6) -----------------------------------------------------------------
+// Cross-stream ordering used to cost the MAIN queue one event-record packet per dependency (ppf_stream_wait_stream: hipEventRecord on the
+// producer's stream): ~70 packets per deit_small step, each a 4-8 us bubble between two dependent kernels (profiles/r6_queue_gaps.txt: 0.74 us
+// per boundary with one stream and no events, 4.7 us with two).  hipExtLaunchKernel can attach a stop event to the dispatch packet itself, so
+// the producer's own completion signal is what the other stream waits for and no extra packet enters the producer's queue.  A stream is
+// "armed" for the duration of one library call by the replay loop (ppf_stream_arm, when the recorded list shows that the call is followed by
+// a wait on its stream); every launch of that call then takes an event from the library's ring, and ppf_stream_wait_stream uses the last
+// one instead of recording.  Unarmed launches (everything outside a replayed step) are plain <<< >>> launches.
+#ifdef __cplusplus
+#include <hip/hip_ext.h>
+hipEvent_t ppf_take_stop_event(hipStream_t s);          // csrc/ppf_runtime.hip; nullptr unless `s` is armed
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                              \
+    do {                                                                                                                               \
+        hipEvent_t ppf_ev_ = ppf_take_stop_event(streamId);                                                                            \
+        if (ppf_ev_) hipExtLaunchKernelGGL(kernelName, dim3(numBlocks), dim3(numThreads), memPerBlock, streamId, nullptr, ppf_ev_, 0, __VA_ARGS__); \
+        else kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                                          \
+    } while (0)
+#endif
+
 // Bijective XCD-aware remap of a 1-D block id: consecutive virtual ids land on the same XCD (private L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;

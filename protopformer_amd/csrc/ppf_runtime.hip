@@ -54,10 +54,36 @@ hipEvent_t ring_event(int64_t seq) {
     }
     return g_ring[i];
 }
+// streams armed for completion events on their launches (ppf_common.h): at most a handful of streams per process
+struct ArmSlot { hipStream_t s; bool used, armed, have; hipEvent_t ev; };
+ArmSlot g_arm[8];
+ArmSlot* arm_slot(hipStream_t s, bool create) {
+    for (auto& a : g_arm) if (a.used && a.s == s) return &a;
+    if (create) for (auto& a : g_arm) if (!a.used) { a = ArmSlot{s, true, false, false, nullptr}; return &a; }
+    return nullptr;
+}
 }  // namespace
+
+// 1: every kernel launch on `stream` carries a completion event from the ring until the stream is disarmed or the event is consumed by
+// ppf_stream_wait_stream(dst, stream); 0: disarm.  Replay loop only (protopformer_amd/_lib.py); never under graph capture.
+int ppf_stream_arm(hipStream_t stream, int on) {
+    ArmSlot* a = arm_slot(stream, on != 0);
+    if (a) { a->armed = on != 0; a->have = false; }
+    return 0;
+}
 
 // everything enqueued on `src` so far happens-before anything enqueued on `dst` after this call
 int ppf_stream_wait_stream(hipStream_t dst, hipStream_t src) {
+    if (ArmSlot* a = arm_slot(src, false)) {
+        const bool use = a->armed && a->have;
+        hipEvent_t aev = a->ev;
+        a->armed = false; a->have = false;
+        if (use) {                                     // the last launch on src carries this event: no packet enters src's queue
+            hipError_t e = hipStreamWaitEvent(dst, aev, 0);
+            if (e != hipSuccess) { ppf_set_error("ppf_stream_wait_stream: %s", hipGetErrorString(e)); return (int)e; }
+            return 0;
+        }
+    }
     hipEvent_t ev = ring_event(g_seq++);
     hipError_t e = hipEventRecord(ev, src);
     if (e == hipSuccess) e = hipStreamWaitEvent(dst, ev, 0);
@@ -92,6 +118,12 @@ bool g_path_on = false;
 }  // namespace
 
 }  // extern "C"
+
+hipEvent_t ppf_take_stop_event(hipStream_t s) {
+    for (auto& a : g_arm)
+        if (a.used && a.armed && a.s == s) { a.ev = ring_event(g_seq++); a.have = true; return a.ev; }
+    return nullptr;
+}
 
 PpfProbeScope::PpfProbeScope(int tag, hipStream_t s, double flops, double bytes) : stream(s) {
     if (!g_path_on || tag < 0 || tag >= PPF_PROBE_NTAGS) return;

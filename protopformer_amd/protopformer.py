@@ -53,7 +53,7 @@ def build_features(base_architecture, pretrained=False, img_size=224, drop_path=
 
 
 # ------------------------------------------------------------------------------------------------ autograd nodes
-_SIDE_FIRST = os.environ.get("PPF_X_PROTO_SIDE_AFTER", "0") == "0"           # (temporary A/B, removed below) the side stream starts on the prototype gradients before the main stream's token-gradient kernels (+1.4 %, round 2)
+_SIDE_FIRST = True           # the side stream starts on the prototype gradients before the main stream's token-gradient kernels (+1.4 % in round 2, +0.6 % again in round 6: profiles/r6_proto_order.txt)
 _KEEP_DIST = os.environ.get("PPF_PROTO_KEEP_DIST", "0") != "0"      # A/B: write and save the (B,P,k) distance map in training as before round 5
 
 
