@@ -863,7 +863,6 @@ __global__ __launch_bounds__(TG_NTHR, 1) void th_grads_kernel(const bf16_t* __re
     const int nqt = (N + QT - 1) / QT, nkb = (N + 15) / 16, nks = (N + 31) / 32;
     // everything enters LDS by LDS-DMA (lane-linear destination, per-lane source).  A tile = QT rows of NPK bf16, contiguous in global
     // memory; rows past N repeat the last one (they meet zero rows of Q / dO).
-    const uint32_t tiles_off = lds_offset_of(tiles);
     auto issue = [&](int qt, int buf) {
         const int chunks = tile_bytes / 16;                    // 16-byte pieces of one tile
         for (int c0 = wave * 64; c0 < chunks; c0 += TG_NTHR) {
@@ -871,11 +870,10 @@ __global__ __launch_bounds__(TG_NTHR, 1) void th_grads_kernel(const bf16_t* __re
             if (c < chunks) {
                 const int row = (c * 16) / (NPK * 2), colb = c * 16 - row * NPK * 2;
                 const size_t src = (size_t)min(qt * QT + row, N - 1) * NPK * 2 + colb;
-                // (through inline assembly, see ppf_common.h lds_dma16_hidden: with the builtin the compiler drained the NEXT tile pair in front of
-                //  the transposed reads of the current one -- s_waitcnt vmcnt(0) before ds_read_b64_tr_b16)
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(tiles_off + buf * 2 * tile_bytes + c0 * 16);
-                lds_dma16_hidden(gds + src, dst);
-                lds_dma16_hidden(ga + src, dst + tile_bytes);
+                // (the builtin, not lds_dma16_hidden: here the compiler's drain in front of the transposed reads measured FASTER in the step --
+                //  cait_xxs24 10 092 vs 10 048 img/s same-box, round 6 -- the next tile pair is small and the wait keeps the eight waves together)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(gds + src), (lds_void*)(tiles + buf * 2 * tile_bytes + c0 * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(ga + src), (lds_void*)(tiles + buf * 2 * tile_bytes + tile_bytes + c0 * 16), 16, 0, 0);
             }
         }
     };
