@@ -32,6 +32,8 @@ def _compile(src, obj):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if "warning:" in r.stderr:                       # (round 6: a reserved-register clobber warning went unseen because stderr was dropped)
+        print(f"[ppf build] warnings from {os.path.basename(src)}:\n{r.stderr[:2000]}", flush=True)
     return src
 
 

@@ -129,7 +129,9 @@ __device__ __forceinline__ void gelu_erf_both2(ppf_float2 x, ppf_float2& g, ppf_
 // (s_waitcnt vmcnt + barrier).  The compiler's own vmcnt bookkeeping for ordinary loads stays safe: loads return in order, so operations it does
 // not know about only make its counted waits stricter.
 __device__ __forceinline__ void lds_dma16_hidden(const void* gptr, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_addr) : "memory", "m0");
+    uint32_t saved_m0;                                   // M0 is the compiler's: saved and restored inside the statement instead of clobbered
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "v"(gptr), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_offset_of(const void* p) { return (uint32_t)(uintptr_t)p; }      // flat LDS address: aperture | offset
 
