@@ -181,10 +181,15 @@ def cpu_baseline():
                                        "sample": f"median of {tiny['timed_steps']} steps after {tiny['warmup']} warm-up, deit_tiny_patch16_224+2000x192 protos, batch 32"}}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/*_pmc_traffic.json, newest round first: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction)."""
-    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+def pmc_traffic(config="deit_small"):
+    """HBM bytes per launch of the dominant kernel (the weight-gradient GEMM group) from the committed PMC passes of this same command and
+    configuration (profiles/r6_*pmc_traffic.json, older rounds for deit_small as a fallback: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    gfx950 2x FETCH correction).  Round 6: every configuration has its own table (deit_tiny, cait_xxs24: profiles/r6_<config>_pmc_traffic.json)."""
+    tag = {"deit_small": "", "deit_tiny": "deit_tiny_", "cait_xxs24": "cait_"}.get(config)
+    if tag is None:
+        return None, None
+    names = [f"r6_{tag}pmc_traffic.json"] + (["r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"] if config == "deit_small" else [])
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -478,7 +483,7 @@ def main():
     if rank == 0:
         ips = world * batch * args.steps / dt
         achieved = (probe_flops / 1e12) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic() if args.config == "deit_small" else (None, None)
+        traffic, traffic_src = pmc_traffic(args.config)
         ex = executed_gflop_per_img(cfg)
         out = {
             "metric": METRIC if args.config == "deit_small" and batch == 256 else

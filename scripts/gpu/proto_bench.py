@@ -27,15 +27,13 @@ t_full = timeit(lambda: ops.proto_fwd(tok, 1, T, pro))
 t_max = timeit(lambda: ops.proto_fwd(tok, 1, T, pro, want_dist=False, want_act=False))
 print(f"proto_fwd full maps {t_full:7.1f} us | max/argmax only {t_max:7.1f} us   (fp32 MFMA floor 240 us, maps 332 MB)")
 
-# global branch (one token per sample) backward: gather kernels vs the dense two-product form
-os.environ.setdefault("PPF_PROTO_BWD_DENSE", "1")
+# global branch (one token per sample) backward: the dense two-product form
 Pg = 2000
 prg = torch.rand(Pg, Dp, generator=g).cuda()
 am, _, dist_g, _ = ops.proto_fwd(tok, 0, 1, prg, want_act=False)
 gg = torch.randn(B, Pg, generator=g).cuda()
 dtok = torch.zeros_like(tok); dpro = torch.zeros_like(prg)
-for mode in ("1", "0"):
-    os.environ["PPF_PROTO_BWD_DENSE"] = mode
+for mode in ("1",):
     t_tok = timeit(lambda: ops.proto_bwd(tok, 0, 1, prg, dist_g, None, gg, None, dtok, None))
     t_pro = timeit(lambda: ops.proto_bwd(tok, 0, 1, prg, dist_g, None, gg, None, None, dpro))
     print(f"T=1 backward, dense={mode}: d tokens {t_tok:7.1f} us | d prototypes {t_pro:7.1f} us")
@@ -48,8 +46,7 @@ for b in range(B):
 gmax = torch.randn(B, P, generator=g).cuda()
 t_tok = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, gfull, gmax, argmax, dtok, None))
 t_pro = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, gfull, gmax, argmax, None, dpro))
-print(f"T=81 backward: d tokens (mark + gather) {t_tok:7.1f} us | d prototypes {t_pro:7.1f} us   (PPF_PROTO_TILED={os.environ.get('PPF_PROTO_TILED', '1')}"
-      f" PPF_PROTO_SG={os.environ.get('PPF_PROTO_SG', 'auto')})")
+print(f"T=81 backward: d tokens (mark + gather) {t_tok:7.1f} us | d prototypes {t_pro:7.1f} us")
 gz = torch.zeros_like(gfull)
 t_z = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, gz, gmax, argmax, None, dpro))
 t_n = timeit(lambda: ops.proto_bwd(tok, 1, T, pro, dist, None, gmax, argmax, None, dpro))
