@@ -102,7 +102,7 @@ def build(cfg, device, seed):
     model = construct_PPNet(cfg["arch"], pretrained=False, img_size=224, prototype_shape=(cfg["P"], cfg["Dp"], 1, 1), num_classes=cfg["C"],
                             reserve_layers=[cfg["layer"]], reserve_token_nums=[cfg["k"]], use_global=True, use_ppc_loss=True, ppc_cov_thresh=1.,
                             ppc_mean_thresh=2., global_coe=0.5, global_proto_per_class=cfg["gpc"], prototype_activation_function="log",
-                            add_on_layers_type="regular")
+                            add_on_layers_type=cfg.get("addon", "regular"))
     model = model.to(device)
     model.train()
     opt = FlatAdamW(model, weight_decay=0.05, ema_decay=0.99996)
@@ -339,6 +339,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the multi-rank launch + all-reduce plumbing (no GPU, no measurement)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
     ap.add_argument("--wgrad-alone", action="store_true", help="(internal) only time the weight-gradient GEMMs of --config on an idle GPU and print that JSON")
+    ap.add_argument("--addon", choices=["regular", "bottleneck"], default="regular",
+                    help="add_on_layers_type: main.py:49 passes 'regular' (the BASELINE configurations); 'bottleneck' is the reference signature's default (not the headline metric)")
+    ap.add_argument("--proto-dim", type=int, default=None, help="prototype width (with --addon bottleneck: < D/2 gives the reference's multi-stage tail)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other two BASELINE configurations after the headline one (--no-cpu-baseline skips them too)")
     args = ap.parse_args()
 
@@ -357,6 +360,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path)")
     cfg = dict(CONFIGS[args.config])
+    cfg["addon"] = args.addon
+    if args.proto_dim:
+        cfg["Dp"] = args.proto_dim
     batch = args.batch or cfg["batch"]
     # test-only: PPF_BENCH_ONE_GPU=1 puts every rank on cuda:0 and makes gloo the process-group backend, so that the whole
     # multi-rank flow of this file (broadcast, chunked all-reduce, guard, replay with live collectives, probe legs) runs on a 1-GPU box
@@ -486,7 +492,7 @@ def main():
         traffic, traffic_src = pmc_traffic(args.config)
         ex = executed_gflop_per_img(cfg)
         out = {
-            "metric": METRIC if args.config == "deit_small" and batch == 256 else
+            "metric": METRIC if args.config == "deit_small" and batch == 256 and args.addon == "regular" and not args.proto_dim else
                       f"images/sec train step, {cfg['arch']}+{cfg['P']} protos, bs{batch}, {world} MI355X ({cfg['label']}; not the headline metric)",
             "value": ips, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
