@@ -180,6 +180,84 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
         }
 }
 
+// The same product for LARGE problems (round 6: the fp32 tail of the reference's default 'bottleneck' add-on head, 20 992 x 384 x 384 per
+// convolution and pass, ran on the 32 x 32 VALU kernel above at ~15 TF/s = +1.2 ms per deit_small step): exact fp32 on the matrix pipe,
+// v_mfma_f32_32x32x2_f32 (an fmaf chain over k, bitwise what the VALU computes in that order).  128 x 128 tile, four waves (2 x 2) with a 64 x 64
+// accumulator tile each, k in chunks of 32 staged through LDS as [k][m] / [k][n] images (pitch 129 floats: conflict-free for both the k-fast and
+// the m-fast global layouts), the next chunk's 32 scalars per thread prefetched into registers under the 64 MFMAs of the current one.
+// Same strided-operand contract and the same split-contraction partials (gridDim.z slices -> sgemm_reduce_kernel) as sgemm_kernel.
+constexpr int SM_T = 128, SM_K = 32, SM_P = SM_T + 1;
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                         float* __restrict__ part, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn,
+                                                         int64_t sbk, int ldc, float alpha, float beta) {
+    __shared__ float sa[SM_K * SM_P], sb[SM_K * SM_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.y * SM_T, n0 = blockIdx.x * SM_T, wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int kchunk = ((K + gridDim.z - 1) / gridDim.z + SM_K - 1) / SM_K * SM_K;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    // element e = tid + 256 i of a 128 x 32 operand chunk: (row r, contraction k); the fast index follows the operand's unit stride
+    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+    float ra[16], rb[16];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i;
+            int r = a_kfast ? e >> 5 : e & 127, k = a_kfast ? e & 31 : e >> 7;
+            ra[i] = (m0 + r < M && k0 + k < kend) ? A[(size_t)(m0 + r) * sam + (size_t)(k0 + k) * sak] : 0.f;
+            r = b_kfast ? e >> 5 : e & 127; k = b_kfast ? e & 31 : e >> 7;
+            rb[i] = (n0 + r < N && k0 + k < kend) ? Bm[(size_t)(n0 + r) * sbn + (size_t)(k0 + k) * sbk] : 0.f;
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i;
+            int r = a_kfast ? e >> 5 : e & 127, k = a_kfast ? e & 31 : e >> 7;
+            sa[k * SM_P + r] = ra[i];
+            r = b_kfast ? e >> 5 : e & 127; k = b_kfast ? e & 31 : e >> 7;
+            sb[k * SM_P + r] = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += SM_K) {
+        __syncthreads();                                       // every wave is done with the previous chunk's images
+        sstore();
+        __syncthreads();
+        if (k0 + SM_K < kend) gload(k0 + SM_K);                // the next chunk travels while this one is multiplied
+#pragma unroll
+        for (int kk = 0; kk < SM_K; kk += 2) {
+            // A operand of the swapped product D[n][m]: lane -> (k = kk + hh, m = .. + l31); B likewise with n
+            const float a0 = sa[(kk + hh) * SM_P + wm + l31], a1 = sa[(kk + hh) * SM_P + wm + 32 + l31];
+            const float b0 = sb[(kk + hh) * SM_P + wn + l31], b1 = sb[(kk + hh) * SM_P + wn + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);      // rows = m (first operand), lanes' column = n
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // accumulator layout of the 32 x 32 MFMAs: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the FIRST operand's index (m)
+    // and column l & 31 of the second (n)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh, n = n0 + wn + 32 * j + l31;
+                if (m < M && n < N) {
+                    if (gridDim.z > 1) part[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
+                    else { float* c = C + (size_t)m * ldc + n; *c = alpha * acc[i][j][r] + (beta != 0.f ? beta * *c : 0.f); }
+                }
+            }
+}
+
 __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, int ldc, int S,
                                                            float alpha, float beta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -304,8 +382,17 @@ int ppf_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, in
     if (S < 1) S = 1;
     const int kchunk = ((K + S - 1) / S + 31) / 32 * 32;
     S = (K + kchunk - 1) / kchunk;                          // no empty slices
-    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, S), dim3(256), 0, stream, A, Bm, C, workspace, M, N, K, sam, sak, sbn, sbk,
-                       ldc, alpha, beta);
+    // large problems (the bottleneck add-on head's tail): the fp32-MFMA kernel; the small deep ones (class-connection logits) stay on the VALU tiles
+    if ((int64_t)M * N * K >= (int64_t(1) << 28) && M >= 64 && N >= 64) {
+        const int tiles = ((N + SM_T - 1) / SM_T) * ((M + SM_T - 1) / SM_T);
+        if (tiles >= 128) S = 1;                              // enough workgroups without splitting the contraction
+        else if (S > 1) { const int kc = ((K + S - 1) / S + SM_K - 1) / SM_K * SM_K; S = (K + kc - 1) / kc; }
+        hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((N + SM_T - 1) / SM_T, (M + SM_T - 1) / SM_T, S), dim3(256), 0, stream, A, Bm, C, workspace, M, N, K,
+                           sam, sak, sbn, sbk, ldc, alpha, beta);
+    } else {
+        hipLaunchKernelGGL(sgemm_kernel, dim3((N + 31) / 32, (M + 31) / 32, S), dim3(256), 0, stream, A, Bm, C, workspace, M, N, K, sam, sak, sbn, sbk,
+                           ldc, alpha, beta);
+    }
     PPF_LAUNCH_CHECK();
     if (S > 1) {
         hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, stream, workspace, C, M, N, ldc, S, alpha, beta);
