@@ -314,14 +314,18 @@ def test_real_shape_train_step_vs_oracle():
     assert worst_cos > 0.992 and rels[len(rels) // 2] < 6e-2 and rels[-1] < 0.4, (rels[len(rels) // 2], rels[-1], worst_cos)
 
 
-def test_two_rank_data_parallel_on_one_gpu():
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_two_rank_data_parallel_on_one_gpu(payload):
     """GradSync + the weight-gradient lane with two real processes (gloo over one GPU; RCCL refuses duplicate devices):
-    identical parameters on both ranks after three steps, and averaged per-rank gradients == full-batch gradients."""
+    identical parameters on both ranks after three steps, and averaged per-rank gradients == full-batch gradients.
+    payload bf16 (round 6, PPF_GRADSYNC_BF16=1): the chunks travel as bf16 -- the replicas must STILL be bit-identical (every rank widens the
+    same all-reduced bf16 values), the averaged gradient agrees with the full-batch one to the wire format's rounding."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29591", os.path.join(root, "scripts", "gpu", "ddp_gloo_check.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+           "--master-port", "29591" if payload == "fp32" else "29593", os.path.join(root, "scripts", "gpu", "ddp_gloo_check.py")]
+    env = dict(os.environ, PPF_GRADSYNC_BF16="1" if payload == "bf16" else "0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     m = re.search(r"ranks identical after 3 steps: (\w+); loss ([0-9.]+); cos\(.*\) = ([0-9.]+)", out)
