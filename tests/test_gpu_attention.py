@@ -93,6 +93,54 @@ def test_attn_masked_rows_known_answer():
     assert float((mass - 1).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("N,mode", [(197, "no-policy"), (82, "no-policy"), (150, "no-policy"), (197, "all-masked-but-self")])
+def test_attn_eps_term_known_answer(N, mode):
+    """The +eps/N term of the policy softmax (deit:42) as a KNOWN ANSWER -- it is 5e-9, invisible to every 1e-3 comparison above, and round 6 moved it
+    out of the per-element arithmetic (one per-row constant of the head-mean map; dropped from the bf16 output of the no-policy kernel).
+    no-policy: every query scores 0 on ONE key and -200 on all others (exp underflows to exactly 0): p = (1 + c) / (1 + eps) there, c / (1 + eps)
+    elsewhere with c = eps / N.  all-masked-but-self: policy 0 everywhere, q = k so that a query's own score is its row maximum: the same two values
+    on / off the diagonal.  N = 197 / 82 take the packed (TAIL) instantiation, 150 the per-element one, the policy case the exact per-element one."""
+    from protopformer_amd import ops
+    B, H, D = 2, 6, 384
+    hd, eps = D // H, 1e-6
+    c = eps / N
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.zeros(B * N, 3 * D)
+    v = torch.randn(B * N, D, generator=g)
+    qkv[:, 2 * D:] = v
+    if mode == "no-policy":
+        u = torch.zeros(hd); u[0] = 40.0                                   # q = 40 e_0; k = -40 e_0 (score -200) except key j* (k = 0: score 0)
+        qkv[:, :D] = u.repeat(H)
+        qkv[:, D:2 * D] = (-u).repeat(H)
+        jstar = 5
+        for b in range(B):
+            qkv[b * N + jstar, D:2 * D] = 0.0
+        pol = None
+    else:
+        k = torch.zeros(B * N, D)
+        k[:, ::hd] = 8.0                                                   # per head: k = 8 e_0 for every token -> every score 8, ties: the self key is kept
+        qkv[:, :D] = k; qkv[:, D:2 * D] = k
+        pol = torch.zeros(B, N).cuda()
+    qkv = qkv.bfloat16()
+    NP = (N + 3) // 4 * 4
+    hm = torch.full((B, N, NP), float("nan"), device="cuda")
+    out, rowmax, zinv = ops.attn_fwd(qkv.cuda(), B, H, N, D, policy=pol, headmean=hm)
+    hm = hm.cpu()
+    big, small = (1 + c) / (1 + eps), c / (1 + eps)
+    exp = torch.full((B, N, N), small)
+    if mode == "no-policy":
+        exp[:, :, jstar] = big
+        ref_out = v.bfloat16().float().reshape(B, N, D)[:, jstar:jstar + 1].expand(B, N, D).reshape(B * N, D)
+    else:
+        exp[:, torch.arange(N), torch.arange(N)] = big
+        ref_out = v.bfloat16().float()
+    assert_close(hm[:, :, :N], exp, rtol=1e-4, atol=0.0, what=f"head-mean map, eps term ({mode}, N={N})")
+    assert float(hm[:, :, N:].abs().max() if NP > N else 0.0) == 0.0
+    assert_close(zinv.cpu(), torch.full((B, H, N), 1 / (1 + eps)), rtol=1e-6, what="1 / (sum + eps)")
+    # output: the selected value row up to bf16 rounding (the eps-weighted sum of the other rows is 1e-6 of max |v|: below the rounding of `out`)
+    assert_close(out.float().cpu(), ref_out, rtol=8e-3, atol=1e-5 * float(v.abs().max()) + 1e-3, what="attention output")
+
+
 @pytest.mark.parametrize("B,H,N,D,use_policy", [(2, 6, 197, 384, False), (2, 3, 197, 192, True), (2, 4, 196, 192, False), (2, 2, 17, 128, True),
                                                  (2, 6, 82, 384, True), (2, 3, 50, 96, True), (3, 4, 128, 128, False)])
 def test_attn_bwd(B, H, N, D, use_policy):
