@@ -538,9 +538,28 @@ def main():
             out["secondary"] = secondary_configs()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_initialized():
+        try:                                      # every rank empties its C stdio buffer (RCCL's banner) BEFORE rank 0 prints the line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            if world > 1:
+                dist.barrier()
+        except Exception:
+            pass
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner to the C library's stdout, where it sits in the buffer until exit -- BEHIND a line printed from Python (seen with
+        # one forced rank in round 6: the JSON line came first, five banner lines after it).  The contract is ONE JSON line, and a consumer that takes the
+        # last line of stdout must find it: flush C stdio first, print the line last.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
